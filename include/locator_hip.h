@@ -1,0 +1,187 @@
+/*
+ * locator_hip.h — C ABI of liblocator_hip.so (gfx950 / MI355X).
+ *
+ * The reference (kr-colab/locator) has no FFI: its hot path is four Python
+ * functions that call Keras (load_network / load_callbacks / train_network /
+ * predict_locs, /root/reference/locator/locator.py:311-470).  This header is
+ * the boundary a maintainer binds instead of `tf.keras`: every entry point
+ * names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types.
+ *   - every pointer is a DEVICE pointer unless the name starts with `h_`.
+ *   - the caller owns every buffer; nothing here allocates or frees device memory.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no
+ *     implicit synchronisation, no global mutable state: safe from several host
+ *     threads / processes on different streams or devices.  Safe to capture
+ *     into a hipGraph.
+ *   - return value: 0 = ok, otherwise a hipError_t (or -1 for a bad argument);
+ *     loc_last_error() returns a thread-local message.
+ *
+ * Data layout
+ *   X      genotypes, uint8, sample-major [n_samples][x_pitch], x_pitch = Kp.
+ *   W1S    layer-1 kernel, fp32, tile-swizzled: element (h,k) lives at
+ *            ((kt*nht + ht)*4 + q)*256 + (hi*32 + kl)*4 + c
+ *          kt=k>>5 kl=k&31 ht=h>>5 q=(h&31)>>3 hi=((h&31)>>2)&1 c=h&3, nht=Hp/32;
+ *          i.e. each (32 SNP x 32 unit) tile is stored in the accumulator
+ *          layout of v_mfma_f32_32x32x2_f32, so a wave streams it with
+ *          fully-coalesced 16-byte loads.  Adam moments use the same layout.
+ *   hidden kernels   fp32 row-major [Hp][Hp] (in x out, the Keras orientation).
+ *   Kp = K rounded up to 32, Hp = width rounded up to 32; padding is zero and
+ *   stays zero under training.
+ */
+#ifndef LOCATOR_HIP_H
+#define LOCATOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOC_ROWS 32 /* rows per row-block = MFMA M; --batch_size <= 32 per launch */
+
+typedef struct loc_dims {
+    int K;     /* SNPs after filtering                        (traingen.shape[1], locator.py:318) */
+    int Kp;    /* K rounded up to a multiple of 32            */
+    int H;     /* --width                                     (locator.py:320)                    */
+    int Hp;    /* H rounded up to a multiple of 32 (<= 512)   */
+    int L;     /* --nlayers: number of Dense+ELU layers, >= 2 (locator.py:319-323)                */
+    int n_pre; /* floor(L/2): ELU layers before Dropout       (locator.py:319)                    */
+} loc_dims;
+
+/* Offsets (in floats) of every tensor inside the flat parameter buffer.
+ * [0, n_trainable) is trainable (Adam m/v buffers have that length);
+ * mov_mean / mov_var follow, so one copy of n_total floats is the
+ * ModelCheckpoint snapshot (locator.py:332-348: all weights incl. BN moving stats). */
+typedef struct loc_layout {
+    int64_t w1;       /* Hp*Kp, swizzled                 */
+    int64_t gamma;    /* Kp                              */
+    int64_t beta;     /* Kp                              */
+    int64_t b1;       /* Hp                              */
+    int64_t wh;       /* (L-1) * Hp*Hp                   */
+    int64_t bh;       /* (L-1) * Hp                      */
+    int64_t wa;       /* Hp*2   Dense(2) #1 (locator.py:324) */
+    int64_t ba;       /* 2                               */
+    int64_t wb;       /* 4      Dense(2) #2 (locator.py:325) */
+    int64_t bb;       /* 2                               */
+    int64_t n_trainable;
+    int64_t mov_mean; /* Kp */
+    int64_t mov_var;  /* Kp */
+    int64_t n_total;
+} loc_layout;
+
+/* Everything a training / inference step needs.  All device pointers. */
+typedef struct loc_net {
+    loc_dims d;
+    float* params;           /* n_total floats                                        */
+    float* adam_m;           /* n_trainable floats                                    */
+    float* adam_v;           /* n_trainable floats                                    */
+    const float* alpha_tab;  /* alpha_tab[t] = sqrt(1-b2^t)/(1-b1^t), t = 0..len-1     */
+    int alpha_tab_len;
+    const float* lr;         /* 1 float: current learning rate (ReduceLROnPlateau)    */
+    const int* t_base;       /* 1 int: Adam steps completed before this graph/epoch   */
+    const uint8_t* X;        /* [n_samples][x_pitch]                                  */
+    int64_t x_pitch;
+    const float* Y;          /* [n_samples][2] z-scored targets (locator.py:284-292)  */
+    float drop_p;            /* --dropout_prop                                        */
+    /* workspace, sized by loc_workspace_floats() */
+    float* ws;
+    int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
+    int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
+} loc_net;
+
+#define LOC_MAX_FWD_GRID 512
+
+const char* loc_last_error(void);
+int loc_version(void);
+
+/* ---- layout helpers (host only) ---- */
+int loc_make_dims(int K, int H, int L, loc_dims* out);
+int loc_param_layout(const loc_dims* d, loc_layout* out);
+int64_t loc_w1s_index(int h, int k, int Hp);
+int64_t loc_workspace_floats(const loc_dims* d);
+
+/* ---- utility kernels ---- */
+/* Keras glorot_uniform init of one Dense kernel (locator.py:319-325 [K]): logical R x C (in x out),
+ * U(+-sqrt(6/(R+C))) from Philox4x32-10 keyed by (seed, stream_id, r*C+c); stored row-major
+ * [Rp][Cp] or (swizzled=1) as W1S with R = SNPs, C = units.  Padding is written as zero. */
+int loc_init_glorot(float* dst, int R, int C, int Rp, int Cp, int swizzled, uint64_t seed, uint64_t stream_id,
+                    void* stream);
+int loc_init_uniform(float* dst, int64_t n, float limit, uint64_t seed, uint64_t stream_id, void* stream);
+/* Keep-masks for Dropout (locator.py:321): mask[i] = philox(seed, offset+i) >= p ? 1 : 0. */
+int loc_dropout_mask_fill(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* Bootstrap resample of SNP columns (locator.py:648-653): dst[r][j] = src[r][site_order[j]]. */
+int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const int32_t* site_order, int K,
+                       uint8_t* dst, int64_t dst_pitch, int n_rows, void* stream);
+/* Row-major (K x H, Keras) <-> swizzled W1S, on device. */
+int loc_w1_swizzle(const float* w_kh, int K, int H, float* w1s, int Kp, int Hp, void* stream);
+int loc_w1_unswizzle(const float* w1s, int Kp, int Hp, float* w_kh, int K, int H, void* stream);
+
+/* ---- BatchNormalization on the input (locator.py:318) ---- */
+/* Training: per-SNP batch mean / biased variance over the n_b rows `rows[0..n_b)`,
+ * out4 = [scale | shift | mean | rstd] (4*Kp), and the moving-statistics update. */
+int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, int K, int Kp,
+                       const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                       float* out4, void* stream);
+/* Inference: scale/shift from the moving statistics. */
+int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const float* beta, const float* mov_mean,
+                             const float* mov_var, float* out4, void* stream);
+
+/* ---- layer 1: Dense(width, elu) on the genotype matrix (locator.py:319-320) ---- */
+/* a1[b][h] = ELU(sum_k xhat[b][k] W1[k][h] + b1[h]) for up to 32 rows; xhat = x*scale+shift.
+ * partial: grid*32*Hp floats of scratch.  mask/a1_drop non-NULL applies Dropout to this layer. */
+int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                   const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
+                   float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream);
+/* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
+ * dW1 and dxhat are never written to memory. */
+int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                         const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
+                         float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
+                         float* b1, float* m_b1, float* v_b1, const float* alpha_tab, int alpha_tab_len,
+                         const float* lr, const int* t_base, int t_off, int grid, void* stream);
+
+/* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
+int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,
+                      const uint8_t* mask, float keep_scale, void* stream);
+/* One backward launch: (a) dz_prev = (dz W^T) * dropmask * ELU'(a_prev);
+ * (b) optionally dW/db + Adam for ANOTHER layer `W2` (the one above), whose old
+ * weights are no longer needed.  Either half may be skipped with NULL pointers. */
+int loc_dense_backward(const float* dz, const float* W, const float* a_prev, const uint8_t* mask,
+                       float keep_scale, float* dz_prev, const float* in2, const float* dz2, float* W2,
+                       float* mW2, float* vW2, float* b2, float* mb2, float* vb2, int Hp,
+                       const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
+                       int t_off, void* stream);
+
+/* ---- Dense(2), Dense(2), euclidean_distance_loss (locator.py:314-315, :324-325) ---- */
+/* Training: loss (batch mean, to *loss_out), head gradients + Adam, dz_last = dA * ELU'(a). */
+int loc_head_train(const float* a, int Hp, int n_b, const int32_t* rows, const float* Y, float* wa, float* ba,
+                   float* wb, float* bb, float* m, float* v, int64_t off_wa, int64_t off_ba, int64_t off_wb,
+                   int64_t off_bb, float* dz_last, float* loss_out, const float* alpha_tab, int alpha_tab_len,
+                   const float* lr, const int* t_base, int t_off, void* stream);
+/* Inference: yhat[b][0..1]; if rows/Y non-NULL also dist[b] = ||yhat - Y[rows[b]]||. */
+int loc_head_eval(const float* a, int Hp, int n_b, const float* wa, const float* ba, const float* wb,
+                  const float* bb, float* yhat, const int32_t* rows, const float* Y, float* dist, void* stream);
+
+/* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
+/* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).
+ * mask: n_b*Hp keep flags for this step (NULL iff drop_p == 0).  loss_out: 1 float.
+ * ev_l1b0 / ev_l1b1: optional hipEvent_t recorded around the layer-1 backward kernel. */
+int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                   float* loss_out, void* ev_l1b0, void* ev_l1b1, void* stream);
+/* Inference forward over n rows (any n >= 0) in blocks of 32: yhat[n][2]; dist[n] if with_targets. */
+int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets, float* dist,
+                void* stream);
+
+/* thin event helpers so a ctypes host can time a kernel on the stream it runs on */
+int loc_event_create(void** ev);
+int loc_event_destroy(void* ev);
+int loc_event_record(void* ev, void* stream);
+int loc_event_elapsed_ms(void* ev0, void* ev1, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCATOR_HIP_H */

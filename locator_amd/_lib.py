@@ -1,0 +1,109 @@
+"""ctypes binding of liblocator_hip.so (C ABI: include/locator_hip.h).
+
+PyTorch is used only as plumbing (device memory, streams, graphs); every kernel on the hot
+path comes from this library.  A missing library is a hard error — there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblocator_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class Dims(C.Structure):
+    _fields_ = [("K", C.c_int), ("Kp", C.c_int), ("H", C.c_int), ("Hp", C.c_int), ("L", C.c_int),
+                ("n_pre", C.c_int)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("w1", "gamma", "beta", "b1", "wh", "bh", "wa", "ba", "wb", "bb",
+                                         "n_trainable", "mov_mean", "mov_var", "n_total")]
+
+
+class Net(C.Structure):
+    _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
+                ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
+                ("Y", vp), ("drop_p", C.c_float), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/locator_hip.h one to one
+SIGNATURES = {
+    "loc_last_error": (C.c_char_p, []),
+    "loc_version": (C.c_int, []),
+    "loc_make_dims": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Dims)]),
+    "loc_param_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout)]),
+    "loc_w1s_index": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "loc_workspace_floats": (C.c_int64, [C.POINTER(Dims)]),
+    "loc_init_glorot": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, vp]),
+    "loc_init_uniform": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
+    "loc_dropout_mask_fill": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
+    "loc_gather_columns": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, C.c_int64, C.c_int, vp]),
+    "loc_w1_swizzle": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "loc_w1_unswizzle": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "loc_bn_batch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "loc_bn_infer_scale_shift": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "loc_l1_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                 C.c_float, vp]),
+    "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    "loc_dense_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, vp]),
+    "loc_dense_backward": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
+                                     C.c_int, vp, vp, C.c_int, vp]),
+    "loc_head_train": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64,
+                                 C.c_int64, C.c_int64, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
+    "loc_head_eval": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
+    "loc_event_create": (C.c_int, [C.POINTER(vp)]),
+    "loc_event_destroy": (C.c_int, [vp]),
+    "loc_event_record": (C.c_int, [vp, vp]),
+    "loc_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+}
+
+
+class LocatorHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liblocator_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LocatorHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C locator_amd/csrc`.  locator_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().loc_last_error().decode(errors="replace")
+        raise LocatorHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def make_dims(K, H, L):
+    d = Dims()
+    check(load().loc_make_dims(int(K), int(H), int(L), C.byref(d)), "loc_make_dims")
+    return d
+
+
+def param_layout(d):
+    lay = Layout()
+    check(load().loc_param_layout(C.byref(d), C.byref(lay)), "loc_param_layout")
+    return lay

@@ -1,0 +1,182 @@
+// C-ABI glue: layout helpers, error plumbing, and the composite step / predict entry points
+// that stand where model.fit's inner step and model.predict stand in the reference
+// (/root/reference/locator/locator.py:367-376, :414, :441).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void loc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* loc_last_error(void) { return g_err; }
+extern "C" int loc_version(void) { return 1; }
+
+extern "C" int loc_make_dims(int K, int H, int L, loc_dims* out) {
+    if (K < 1 || H < 1 || H > 512 || L < 2) {
+        loc_set_error("loc_make_dims: need K >= 1, 1 <= width <= 512, nlayers >= 2 (got K=%d H=%d L=%d)", K, H, L);
+        return -1;
+    }
+    out->K = K;
+    out->Kp = (K + 31) / 32 * 32;
+    out->H = H;
+    out->Hp = (H + 31) / 32 * 32;
+    out->L = L;
+    out->n_pre = L / 2;
+    return 0;
+}
+
+extern "C" int loc_param_layout(const loc_dims* d, loc_layout* o) {
+    int64_t off = 0;
+    const int64_t Kp = d->Kp, Hp = d->Hp, L = d->L;
+    o->w1 = off;    off += Hp * Kp;
+    o->gamma = off; off += Kp;
+    o->beta = off;  off += Kp;
+    o->b1 = off;    off += Hp;
+    o->wh = off;    off += (L - 1) * Hp * Hp;
+    o->bh = off;    off += (L - 1) * Hp;
+    o->wa = off;    off += Hp * 2;
+    o->ba = off;    off += 2;
+    o->wb = off;    off += 4;
+    o->bb = off;    off += 2;
+    off = (off + 3) / 4 * 4;
+    o->n_trainable = off;
+    o->mov_mean = off; off += Kp;
+    o->mov_var = off;  off += Kp;
+    o->n_total = off;
+    return 0;
+}
+
+extern "C" int64_t loc_w1s_index(int h, int k, int Hp) { return w1s_index(h, k, Hp / 32); }
+
+struct ws_view {
+    float *bn4, *partial, *acts, *adrop, *dz;
+};
+static ws_view carve(const loc_dims* d, float* ws) {
+    ws_view v;
+    const int64_t blk = 32 * (int64_t)d->Hp;
+    v.bn4 = ws;
+    v.partial = v.bn4 + 4 * (int64_t)d->Kp;
+    v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk;
+    v.adrop = v.acts + d->L * blk;
+    v.dz = v.adrop + blk;
+    return v;
+}
+extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
+    const int64_t blk = 32 * (int64_t)d->Hp;
+    return 4 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk;
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int rc__ = (x);        \
+        if (rc__) return rc__; \
+    } while (0)
+
+extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                              float* loss_out, void* ev_l1b0, void* ev_l1b1, void* stream) {
+    const loc_dims* d = &net->d;
+    if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_train_step: n_b=%d out of 1..32", n_b); return -1; }
+    const bool use_drop = net->drop_p > 0.f;
+    if (use_drop && !mask) { loc_set_error("loc_train_step: dropout_prop > 0 needs a keep mask"); return -1; }
+    const float ks = use_drop ? 1.0f / (1.0f - net->drop_p) : 1.0f;
+    loc_layout lay;
+    loc_param_layout(d, &lay);
+    float *P = net->params, *M = net->adam_m, *V = net->adam_v;
+    ws_view w = carve(d, net->ws);
+    const int Hp = d->Hp, L = d->L, npre = d->n_pre;
+    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    auto act = [&](int l) { return w.acts + (l - 1) * blk; };        // ELU output of layer l (1-based)
+    auto dzl = [&](int l) { return w.dz + (l - 1) * blk; };          // dLoss/dz of layer l
+    auto in_of = [&](int l) { return (use_drop && l - 1 == npre) ? w.adrop : act(l - 1); };  // input of layer l >= 2
+    const float* at = net->alpha_tab;
+    const int atl = net->alpha_tab_len;
+
+    TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
+                           P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
+    {
+        const bool dr = use_drop && npre == 1;
+        TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
+                           net->l1_fwd_grid, act(1), dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
+    }
+    for (int l = 2; l <= L; ++l) {
+        const bool dr = use_drop && l == npre;
+        TRY(loc_dense_forward(in_of(l), P + lay.wh + (l - 2) * HH, P + lay.bh + (int64_t)(l - 2) * Hp, Hp, act(l),
+                              dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
+    }
+    TRY(loc_head_train(act(L), Hp, n_b, rows, net->Y, P + lay.wa, P + lay.ba, P + lay.wb, P + lay.bb, M, V, lay.wa,
+                       lay.ba, lay.wb, lay.bb, dzl(L), loss_out, at, atl, net->lr, net->t_base, t_off, stream));
+    for (int l = L; l >= 2; --l) {
+        // dx through layer l; dW/Adam for layer l+1 (its dx was produced by the previous launch)
+        const bool dr = use_drop && l - 1 == npre;
+        const bool dw = l + 1 <= L;
+        TRY(loc_dense_backward(dzl(l), P + lay.wh + (l - 2) * HH, act(l - 1), dr ? mask : nullptr, ks, dzl(l - 1),
+                               dw ? in_of(l + 1) : nullptr, dw ? dzl(l + 1) : nullptr,
+                               dw ? P + lay.wh + (l - 1) * HH : nullptr, dw ? M + lay.wh + (l - 1) * HH : nullptr,
+                               dw ? V + lay.wh + (l - 1) * HH : nullptr,
+                               dw ? P + lay.bh + (int64_t)(l - 1) * Hp : nullptr,
+                               dw ? M + lay.bh + (int64_t)(l - 1) * Hp : nullptr,
+                               dw ? V + lay.bh + (int64_t)(l - 1) * Hp : nullptr, Hp, at, atl, net->lr, net->t_base,
+                               t_off, stream));
+    }
+    // dW/Adam for layer 2
+    TRY(loc_dense_backward(nullptr, nullptr, nullptr, nullptr, ks, nullptr, in_of(2), dzl(2), P + lay.wh,
+                           M + lay.wh, V + lay.wh, P + lay.bh, M + lay.bh, V + lay.bh, Hp, at, atl, net->lr,
+                           net->t_base, t_off, stream));
+    if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
+    TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
+                             P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
+                             P + lay.b1, M + lay.b1, V + lay.b1, at, atl, net->lr, net->t_base, t_off,
+                             net->l1_bwd_grid, stream));
+    if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets,
+                           float* dist, void* stream) {
+    if (n <= 0) return 0;
+    const loc_dims* d = &net->d;
+    loc_layout lay;
+    loc_param_layout(d, &lay);
+    const float* P = net->params;
+    ws_view w = carve(d, net->ws);
+    const int Hp = d->Hp, L = d->L;
+    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,
+                                 w.bn4, stream));
+    for (int i = 0; i < n; i += LOC_ROWS) {
+        const int nb = n - i < LOC_ROWS ? n - i : LOC_ROWS;
+        TRY(loc_l1_forward(net->X, net->x_pitch, rows + i, nb, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
+                           net->l1_fwd_grid, w.acts, nullptr, nullptr, 1.f, stream));
+        for (int l = 2; l <= L; ++l)
+            TRY(loc_dense_forward(w.acts + (l - 2) * blk, P + lay.wh + (l - 2) * HH,
+                                  P + lay.bh + (int64_t)(l - 2) * Hp, Hp, w.acts + (l - 1) * blk, nullptr, nullptr,
+                                  1.f, stream));
+        TRY(loc_head_eval(w.acts + (L - 1) * blk, Hp, nb, P + lay.wa, P + lay.ba, P + lay.wb, P + lay.bb,
+                          yhat + 2 * (int64_t)i, with_targets ? rows + i : nullptr, with_targets ? net->Y : nullptr,
+                          with_targets ? dist + i : nullptr, stream));
+    }
+    return 0;
+}
+
+extern "C" int loc_event_create(void** ev) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) { loc_set_error("hipEventCreate: %s", hipGetErrorString(rc)); return (int)rc; }
+    *ev = (void*)e;
+    return 0;
+}
+extern "C" int loc_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int loc_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+extern "C" int loc_event_elapsed_ms(void* ev0, void* ev1, float* ms) {
+    hipError_t rc = hipEventSynchronize((hipEvent_t)ev1);
+    if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)ev0, (hipEvent_t)ev1);
+    if (rc != hipSuccess) { loc_set_error("hipEventElapsedTime: %s", hipGetErrorString(rc)); return (int)rc; }
+    return 0;
+}

@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA f32 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/locator_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BN_EPS 1e-3f
+#define BN_MOMENTUM 0.99f
+#define ADAM_C1 0.1f     /* (float)(1 - 0.9)   */
+#define ADAM_C2 0.001f   /* (float)(1 - 0.999) */
+#define ADAM_EPS 1e-7f
+
+// Row of accumulator register r in lane-half hi for v_mfma_f32_32x32x2_f32:
+// D[i][j]: j = lane & 31, i = rowmap(r, lane >> 5).
+__device__ __forceinline__ int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+// ELU'(z) from the activation value a = ELU(z):  1 if z > 0 else e^z = a + 1
+__device__ __forceinline__ float elu_grad_from_act(float a) { return a > 0.f ? 1.f : a + 1.f; }
+
+// Keras Adam: eps outside the root, bias correction folded into alpha.
+__device__ __forceinline__ void adam_update(float& w, float& m, float& v, float g, float alpha) {
+    m = m + (g - m) * ADAM_C1;
+    v = v + (g * g - v) * ADAM_C2;
+    w = w - (m * alpha) / (sqrtf(v) + ADAM_EPS);
+}
+
+__device__ __forceinline__ float adam_alpha(const float* alpha_tab, int alpha_tab_len, const float* lr,
+                                            const int* t_base, int t_off) {
+    int t = t_base[0] + t_off;
+    if (t >= alpha_tab_len) t = alpha_tab_len - 1;
+    return lr[0] * alpha_tab[t];
+}
+
+// ---- Philox4x32-10 counter RNG -------------------------------------------------
+struct philox4 {
+    uint32_t v[4];
+};
+__host__ __device__ inline philox4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    philox4 r;
+    r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+    return r;
+}
+
+// W1S index of element (h, k): see include/locator_hip.h
+__host__ __device__ inline int64_t w1s_index(int h, int k, int nht) {
+    int kt = k >> 5, kl = k & 31, ht = h >> 5, hl = h & 31;
+    int q = hl >> 3, hi = (hl >> 2) & 1, c = hl & 3;
+    return ((int64_t)(kt * nht + ht) * 4 + q) * 256 + (hi * 32 + kl) * 4 + c;
+}
+
+// host-side error plumbing (api.hip)
+void loc_set_error(const char* fmt, ...);
+#define LOC_CHECK_LAUNCH()                                              \
+    do {                                                                \
+        hipError_t e__ = hipGetLastError();                             \
+        if (e__ != hipSuccess) {                                        \
+            loc_set_error("%s: %s", __func__, hipGetErrorString(e__));  \
+            return (int)e__;                                            \
+        }                                                               \
+    } while (0)

@@ -1,0 +1,123 @@
+// Utility kernels: Glorot init, dropout keep-masks, bootstrap column gather, W1 layout conversion.
+#include "common.h"
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)r + 0.5f) * 2.3283064365386963e-10f; }
+
+// Logical matrix R x C (Keras kernel, in x out), value(r, c) keyed by the counter r*C + c so the
+// same seed gives the same logical matrix whatever the storage layout.  Storage: swizzled W1S
+// (r = SNP k, c = unit h) or row-major [Rp][Cp]; padding is written as zero.
+__global__ void init_glorot_kernel(float* __restrict__ dst, int R, int C, int Rp, int Cp, int swizzled, float limit,
+                                   uint64_t seed, uint64_t stream_id) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Rp * Cp) return;
+    int r = (int)(i / Cp), c = (int)(i % Cp);
+    float val = 0.f;
+    if (r < R && c < C) {
+        philox4 p = philox4x32_10((uint64_t)r * (uint64_t)C + (uint64_t)c, stream_id, seed);
+        val = (2.f * u01(p.v[0]) - 1.f) * limit;
+    }
+    int64_t o = swizzled ? w1s_index(c, r, Cp / 32) : i;
+    dst[o] = val;
+}
+
+__global__ void init_uniform_kernel(float* __restrict__ dst, int64_t n, float limit, uint64_t seed,
+                                    uint64_t stream_id) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * j >= n) return;
+    philox4 p = philox4x32_10((uint64_t)j, stream_id, seed);
+    for (int c = 0; c < 4; ++c)
+        if (4 * j + c < n) dst[4 * j + c] = (2.f * u01(p.v[c]) - 1.f) * limit;
+}
+
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t n, uint32_t thresh, uint64_t seed,
+                                    uint64_t offset4) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * j >= n) return;
+    philox4 p = philox4x32_10(offset4 + (uint64_t)j, 0x6d61736bULL /* "mask" */, seed);
+    for (int c = 0; c < 4; ++c)
+        if (4 * j + c < n) mask[4 * j + c] = p.v[c] >= thresh ? 1 : 0;
+}
+
+__global__ void gather_columns_kernel(const uint8_t* __restrict__ src, int64_t src_pitch,
+                                      const int32_t* __restrict__ site_order, int K, uint8_t* __restrict__ dst,
+                                      int64_t dst_pitch) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (j >= K) return;
+    dst[(int64_t)r * dst_pitch + j] = src[(int64_t)r * src_pitch + site_order[j]];
+}
+
+__global__ void w1_swizzle_kernel(const float* __restrict__ w_kh, int K, int H, float* __restrict__ w1s, int Kp,
+                                  int Hp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Kp * Hp) return;
+    int k = (int)(i / Hp), h = (int)(i % Hp);
+    w1s[w1s_index(h, k, Hp / 32)] = (k < K && h < H) ? w_kh[(int64_t)k * H + h] : 0.f;
+}
+
+__global__ void w1_unswizzle_kernel(const float* __restrict__ w1s, int Hp, float* __restrict__ w_kh, int K, int H) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K * H) return;
+    int k = (int)(i / H), h = (int)(i % H);
+    w_kh[i] = w1s[w1s_index(h, k, Hp / 32)];
+}
+
+extern "C" int loc_init_glorot(float* dst, int R, int C, int Rp, int Cp, int swizzled, uint64_t seed,
+                               uint64_t stream_id, void* stream) {
+    if (swizzled && (Rp % 32 || Cp % 32)) { loc_set_error("loc_init_glorot: swizzled needs Rp,Cp %% 32 == 0"); return -1; }
+    double limit = sqrt(6.0 / ((double)R + (double)C));
+    int64_t n = (int64_t)Rp * Cp;
+    hipLaunchKernelGGL(init_glorot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst,
+                       R, C, Rp, Cp, swizzled, (float)limit, seed, stream_id);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_init_uniform(float* dst, int64_t n, float limit, uint64_t seed, uint64_t stream_id,
+                                void* stream) {
+    if (n <= 0) return 0;
+    int64_t nt = (n + 3) / 4;
+    hipLaunchKernelGGL(init_uniform_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dst, n, limit, seed, stream_id);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_dropout_mask_fill(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                     void* stream) {
+    if (n <= 0) return 0;
+    if (offset % 4) { loc_set_error("loc_dropout_mask_fill: offset must be a multiple of 4"); return -1; }
+    if (!(p >= 0.f && p < 1.f)) { loc_set_error("loc_dropout_mask_fill: p=%f out of [0,1)", p); return -1; }
+    uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    int64_t nt = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       mask, n, thresh, seed, offset / 4);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const int32_t* site_order, int K,
+                                  uint8_t* dst, int64_t dst_pitch, int n_rows, void* stream) {
+    if (n_rows <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((K + 255) / 256, n_rows), dim3(256), 0, (hipStream_t)stream, src,
+                       src_pitch, site_order, K, dst, dst_pitch);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_w1_swizzle(const float* w_kh, int K, int H, float* w1s, int Kp, int Hp, void* stream) {
+    int64_t n = (int64_t)Kp * Hp;
+    hipLaunchKernelGGL(w1_swizzle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kh,
+                       K, H, w1s, Kp, Hp);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_w1_unswizzle(const float* w1s, int Kp, int Hp, float* w_kh, int K, int H, void* stream) {
+    int64_t n = (int64_t)K * H;
+    (void)Kp;
+    hipLaunchKernelGGL(w1_unswizzle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1s,
+                       Hp, w_kh, K, H);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

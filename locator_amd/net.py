@@ -1,0 +1,217 @@
+"""Device-side model state for locator's network (reference: load_network,
+/root/reference/locator/locator.py:311-327) and thin wrappers over the C-ABI entry points.
+
+torch is plumbing here: it owns device buffers and streams.  All arithmetic is in
+liblocator_hip.so.  Layouts are described in include/locator_hip.h and DESIGN.md §3.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ALPHA_TAB_LEN = 32769            # beyond this t the Adam bias correction is 1 to fp32 precision
+ADAM_B1, ADAM_B2 = 0.9, 0.999
+LOC_ROWS = 32
+LOC_MAX_FWD_GRID = 512
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.LocatorHipError("locator_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback.")
+
+
+def upload_genotypes(x_nk, device="cuda:0"):
+    """(n_samples, K) integer allele counts -> device uint8 [n_samples][Kp] with zero padding.
+    This is the layout `traingen` already has in the reference (locator.py:303)."""
+    x_nk = np.ascontiguousarray(x_nk)
+    n, K = x_nk.shape
+    Kp = (K + 31) // 32 * 32
+    host = np.zeros((n, Kp), np.uint8)
+    host[:, :K] = x_nk.astype(np.uint8, copy=False)
+    return torch.from_numpy(host).to(device)
+
+
+class LocatorNet:
+    """BatchNormalization -> nlayers x Dense(width, elu) with Dropout in the middle -> Dense(2) -> Dense(2),
+    Adam, Euclidean loss — the model of locator.py:311-327, resident on one GPU."""
+
+    def __init__(self, X, Y, K, width=256, nlayers=10, dropout_prop=0.25, seed=0, replicate=0, device="cuda:0"):
+        require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.d = _lib.make_dims(K, width, nlayers)
+        self.lay = _lib.param_layout(self.d)
+        assert X.dtype == torch.uint8 and X.is_cuda and X.shape[1] == self.d.Kp and X.is_contiguous()
+        assert Y.dtype == torch.float32 and Y.is_cuda and Y.shape[1] == 2 and Y.is_contiguous()
+        self.X, self.Y = X, Y
+        self.drop_p = float(dropout_prop)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.replicate = int(replicate)
+        dev = self.device
+        self.params = torch.zeros(self.lay.n_total, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.lay.n_trainable, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(self.lay.n_trainable, dtype=torch.float32, device=dev)
+        self.best = None
+        t = np.arange(ALPHA_TAB_LEN, dtype=np.float64)
+        tab = np.ones(ALPHA_TAB_LEN)
+        tab[1:] = np.sqrt(1.0 - ADAM_B2 ** t[1:]) / (1.0 - ADAM_B1 ** t[1:])
+        self.alpha_tab = torch.from_numpy(tab.astype(np.float32)).to(dev)
+        self.lr_t = torch.full((1,), 1e-3, dtype=torch.float32, device=dev)
+        self.t_base_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws = torch.empty(self.lib.loc_workspace_floats(C.byref(self.d)), dtype=torch.float32, device=dev)
+        nkt = self.d.Kp // 32
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
+        self.l1_bwd_grid = max(1, min(nkt, 3 * ncu))
+        self._net = None
+        self.init_weights()
+
+    # ------------------------------------------------------------------ C struct
+    def cnet(self):
+        n = _lib.Net()
+        n.d = self.d
+        n.params, n.adam_m, n.adam_v = self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        n.alpha_tab, n.alpha_tab_len = self.alpha_tab.data_ptr(), ALPHA_TAB_LEN
+        n.lr, n.t_base = self.lr_t.data_ptr(), self.t_base_t.data_ptr()
+        n.X, n.x_pitch, n.Y = self.X.data_ptr(), self.X.stride(0), self.Y.data_ptr()
+        n.drop_p = self.drop_p
+        n.ws = self.ws.data_ptr()
+        n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
+        self._net = n
+        return n
+
+    # ------------------------------------------------------------------ parameters
+    def _sec(self, name, n):
+        off = getattr(self.lay, name)
+        return self.params[off:off + n]
+
+    def init_weights(self):
+        """Keras defaults [K]: glorot_uniform kernels, zero biases, gamma=1, beta=0, moving mean 0 / var 1
+        (SURVEY.md A.1).  Streams are keyed by (seed, replicate, layer) so a replicate's init does not
+        depend on which GPU or in which order it runs."""
+        d, lay, lib = self.d, self.lay, self.lib
+        self.params.zero_()
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self._sec("gamma", d.K).fill_(1.0)
+        self._sec("mov_var", d.K).fill_(1.0)
+        sid = lambda layer: (self.replicate << 16) | layer
+        p = self.params.data_ptr()
+        st = _stream()
+        _lib.check(lib.loc_init_glorot(p + 4 * lay.w1, d.K, d.H, d.Kp, d.Hp, 1, self.seed, sid(0), st), "init W1")
+        for i in range(d.L - 1):
+            _lib.check(lib.loc_init_glorot(p + 4 * (lay.wh + i * d.Hp * d.Hp), d.H, d.H, d.Hp, d.Hp, 0, self.seed,
+                                           sid(1 + i), st), "init Wh")
+        _lib.check(lib.loc_init_glorot(p + 4 * lay.wa, d.H, 2, d.Hp, 2, 0, self.seed, sid(d.L), st), "init Wa")
+        _lib.check(lib.loc_init_glorot(p + 4 * lay.wb, 2, 2, 2, 2, 0, self.seed, sid(d.L + 1), st), "init Wb")
+        self.t_base_t.zero_()
+        self.lr_t.fill_(1e-3)
+
+    def _export_flat(self, flat, with_moving=True):
+        """Flat device buffer -> dict in the oracle's format (Keras orientation, un-padded)."""
+        d, lay, lib = self.d, self.lay, self.lib
+        out = {}
+        w1 = torch.empty((d.K, d.H), dtype=torch.float32, device=self.device)
+        _lib.check(lib.loc_w1_unswizzle(flat.data_ptr() + 4 * lay.w1, d.Kp, d.Hp, w1.data_ptr(), d.K, d.H, _stream()),
+                   "unswizzle")
+        W = [w1.cpu().numpy()]
+        b = [flat[lay.b1:lay.b1 + d.H].cpu().numpy()]
+        for i in range(d.L - 1):
+            wh = flat[lay.wh + i * d.Hp * d.Hp: lay.wh + (i + 1) * d.Hp * d.Hp].view(d.Hp, d.Hp)
+            W.append(wh[:d.H, :d.H].cpu().numpy().copy())
+            b.append(flat[lay.bh + i * d.Hp: lay.bh + i * d.Hp + d.H].cpu().numpy())
+        W.append(flat[lay.wa:lay.wa + 2 * d.Hp].view(d.Hp, 2)[:d.H].cpu().numpy().copy())
+        b.append(flat[lay.ba:lay.ba + 2].cpu().numpy())
+        W.append(flat[lay.wb:lay.wb + 4].view(2, 2).cpu().numpy().copy())
+        b.append(flat[lay.bb:lay.bb + 2].cpu().numpy())
+        out["W"], out["b"] = W, b
+        out["gamma"] = flat[lay.gamma:lay.gamma + d.K].cpu().numpy()
+        out["beta"] = flat[lay.beta:lay.beta + d.K].cpu().numpy()
+        if with_moving:
+            out["mov_mean"] = flat[lay.mov_mean:lay.mov_mean + d.K].cpu().numpy()
+            out["mov_var"] = flat[lay.mov_var:lay.mov_var + d.K].cpu().numpy()
+        return out
+
+    def export_params(self):
+        return self._export_flat(self.params)
+
+    def export_adam(self):
+        return self._export_flat(self.adam_m, False), self._export_flat(self.adam_v, False)
+
+    def _import_flat(self, flat, p, with_moving=True):
+        d, lay, lib = self.d, self.lay, self.lib
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        flat.zero_()
+        w1 = f32(p["W"][0])
+        _lib.check(lib.loc_w1_swizzle(w1.data_ptr(), d.K, d.H, flat.data_ptr() + 4 * lay.w1, d.Kp, d.Hp, _stream()),
+                   "swizzle")
+        torch.cuda.current_stream().synchronize()
+        flat[lay.b1:lay.b1 + d.H] = f32(p["b"][0])
+        for i in range(d.L - 1):
+            wh = flat[lay.wh + i * d.Hp * d.Hp: lay.wh + (i + 1) * d.Hp * d.Hp].view(d.Hp, d.Hp)
+            wh[:d.H, :d.H] = f32(p["W"][1 + i])
+            flat[lay.bh + i * d.Hp: lay.bh + i * d.Hp + d.H] = f32(p["b"][1 + i])
+        flat[lay.wa:lay.wa + 2 * d.Hp].view(d.Hp, 2)[:d.H] = f32(p["W"][d.L])
+        flat[lay.ba:lay.ba + 2] = f32(p["b"][d.L])
+        flat[lay.wb:lay.wb + 4] = f32(p["W"][d.L + 1]).reshape(-1)
+        flat[lay.bb:lay.bb + 2] = f32(p["b"][d.L + 1])
+        flat[lay.gamma:lay.gamma + d.K] = f32(p["gamma"])
+        flat[lay.beta:lay.beta + d.K] = f32(p["beta"])
+        if with_moving:
+            flat[lay.mov_mean:lay.mov_mean + d.K] = f32(p["mov_mean"])
+            flat[lay.mov_var:lay.mov_var + d.K] = f32(p["mov_var"])
+
+    def import_params(self, p):
+        self._import_flat(self.params, p)
+
+    # ------------------------------------------------------------------ ops
+    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None):
+        """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
+        mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view."""
+        net = self._net or self.cnet()
+        _lib.check(self.lib.loc_train_step(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
+                                           _ptr(loss_out), ev0, ev1, _stream()), "loc_train_step")
+
+    def predict_rows(self, rows, n, yhat, dist=None):
+        """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
+        net = self._net or self.cnet()
+        _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
+                                        _ptr(dist), _stream()), "loc_predict")
+
+    def fill_dropout_masks(self, mask_buf, n, offset):
+        _lib.check(self.lib.loc_dropout_mask_fill(_ptr(mask_buf), int(n), self.drop_p,
+                                                  (self.seed ^ 0x64726F70) + (self.replicate << 40), int(offset),
+                                                  _stream()), "loc_dropout_mask_fill")
+
+    def snapshot(self):
+        """ModelCheckpoint(save_best_only, save_weights_only) as a device-side copy (locator.py:332-348)."""
+        if self.best is None:
+            self.best = torch.empty_like(self.params)
+        self.best.copy_(self.params)
+
+    def restore_best(self):
+        """model.load_weights(best) (locator.py:379-388)."""
+        if self.best is not None:
+            self.params.copy_(self.best)
+
+
+def gather_columns(X, site_order, K):
+    """Bootstrap resample of SNP columns on device (locator.py:648-653)."""
+    lib = _lib.load()
+    so = torch.as_tensor(np.asarray(site_order, dtype=np.int32)).to(X.device)
+    out = torch.zeros_like(X)
+    _lib.check(lib.loc_gather_columns(_ptr(X), X.stride(0), _ptr(so), int(K), _ptr(out), out.stride(0),
+                                      X.shape[0], _stream()), "loc_gather_columns")
+    return out

@@ -1,0 +1,164 @@
+"""model.fit + the three Keras callbacks, MI355X edition (reference: load_callbacks / train_network,
+/root/reference/locator/locator.py:330-394; semantics restated in SURVEY.md A.4/A.5).
+
+One epoch = ceil(n_train / batch) minibatch steps (partial last batch kept) + one validation
+sweep in inference mode.  The whole epoch is captured once into a HIP graph and replayed; the
+host only refreshes the permutation, reads back the per-step losses and validation distances,
+and runs the callback state machines.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .net import LOC_ROWS, LocatorNet
+
+
+class Callbacks:
+    """ModelCheckpoint(best only) -> EarlyStopping -> ReduceLROnPlateau on val_loss, in that order
+    (locator.py:362).  All comparisons are strict '<' with min_delta 0 (locator.py:349-361)."""
+
+    def __init__(self, patience=100, lr0=1e-3):
+        self.patience = int(patience)
+        self.lr_patience = int(patience / 6)          # locator.py:354
+        self.lr = float(np.float32(lr0))              # Keras keeps the LR in an fp32 variable
+        self.ck_best = np.inf
+        self.es_best = np.inf
+        self.es_wait = 0
+        self.rl_best = np.inf
+        self.rl_wait = 0
+
+    def on_epoch_end(self, epoch, val_loss):
+        lr_logged = self.lr
+        save = val_loss < self.ck_best
+        if save:
+            self.ck_best = val_loss
+        self.es_wait += 1
+        if val_loss < self.es_best:
+            self.es_best = val_loss
+            self.es_wait = 0
+        stop = self.es_wait >= self.patience and epoch > 0
+        if val_loss < self.rl_best:
+            self.rl_best = val_loss
+            self.rl_wait = 0
+        else:
+            self.rl_wait += 1
+            if self.rl_wait >= self.lr_patience:
+                self.lr = float(np.float32(max(np.float32(self.lr) * np.float32(0.5), 0.0)))
+                self.rl_wait = 0
+        return save, stop, lr_logged
+
+
+class History:
+    """Stand-in for keras.callbacks.History: `.history` is a dict of per-epoch lists in Keras 3
+    column order loss, val_loss, learning_rate (locator.py:468, :479-482)."""
+
+    def __init__(self):
+        self.history = {"loss": [], "val_loss": [], "learning_rate": []}
+        self.epoch_seconds = []
+
+
+class EpochRunner:
+    """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
+
+    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True):
+        if not 1 <= batch_size <= LOC_ROWS:
+            raise ValueError(f"--batch_size must be in 1..{LOC_ROWS} for the HIP path (got {batch_size})")
+        self.net = net
+        dev = net.device
+        self.batch = int(batch_size)
+        self.train_rows = np.asarray(train_rows, dtype=np.int32)
+        self.n_train = len(self.train_rows)
+        self.steps = (self.n_train + self.batch - 1) // self.batch
+        self.n_val = len(val_rows)
+        self.val_rows = torch.as_tensor(np.asarray(val_rows, dtype=np.int32)).to(dev)
+        self.perm_host = torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory()
+        self.perm_dev = torch.zeros(self.steps * self.batch, dtype=torch.int32, device=dev)
+        Hp = net.d.Hp
+        self.mask_stride = LOC_ROWS * Hp
+        self.masks = (torch.zeros(self.steps * self.mask_stride, dtype=torch.uint8, device=dev)
+                      if net.drop_p > 0 else None)
+        self.stats = torch.zeros(self.steps + max(self.n_val, 1), dtype=torch.float32, device=dev)
+        self.stats_host = torch.empty_like(self.stats, device="cpu").pin_memory()
+        self.val_yhat = torch.zeros((max(self.n_val, 1), 2), dtype=torch.float32, device=dev)
+        self.use_graph = use_graph
+        self.graph = None
+        self.epochs_run = 0
+        self.step_sizes = np.array([min(self.batch, self.n_train - j * self.batch) for j in range(self.steps)])
+        net.cnet()
+
+    def enqueue(self, ev=None):
+        net = self.net
+        for j in range(self.steps):
+            nb = int(self.step_sizes[j])
+            mask = self.masks[j * self.mask_stride:] if self.masks is not None else None
+            e0, e1 = (ev[j] if ev is not None else (None, None))
+            net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1)
+        if self.n_val:
+            net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
+        net.t_base_t.add_(self.steps)
+
+    def run_epoch(self, perm, ev=None):
+        """perm: permutation of range(n_train) (Keras shuffle=True draws it unseeded; here it is an input)."""
+        net = self.net
+        rows = self.train_rows[np.asarray(perm)]
+        self.perm_host[:self.n_train] = torch.from_numpy(rows)
+        self.perm_host[self.n_train:] = 0
+        self.perm_dev.copy_(self.perm_host, non_blocking=True)
+        if self.masks is not None:
+            net.fill_dropout_masks(self.masks, self.masks.numel(), self.epochs_run * self.masks.numel())
+        if self.use_graph and ev is None:
+            if self.graph is None and self.epochs_run >= 1:      # epoch 0 ran eagerly = warm-up
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.enqueue()
+                self.graph = g
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.enqueue()
+        else:
+            self.enqueue(ev)
+        self.stats_host.copy_(self.stats, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.epochs_run += 1
+        s = self.stats_host.numpy()
+        loss = float(np.dot(s[:self.steps].astype(np.float64), self.step_sizes) / self.n_train)
+        val = float(s[self.steps:self.steps + self.n_val].astype(np.float64).mean()) if self.n_val else float("nan")
+        return loss, val
+
+
+def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, perm_fn=None,
+        use_graph=True, verbose=0, log=print):
+    """train_network (locator.py:365-394): fit with checkpoint / early-stop / LR-plateau callbacks, then
+    reload the best weights.  Returns a History."""
+    runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph)
+    cb = Callbacks(patience, 1e-3)
+    hist = History()
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))
+    if perm_fn is None:
+        perm_fn = lambda epoch: rng.permutation(runner.n_train)
+    net.lr_t.fill_(cb.lr)
+    for epoch in range(max_epochs):
+        t0 = time.perf_counter()
+        loss, val = runner.run_epoch(perm_fn(epoch))
+        save, stop, lr_logged = cb.on_epoch_end(epoch, val)
+        hist.history["loss"].append(loss)
+        hist.history["val_loss"].append(val)
+        hist.history["learning_rate"].append(lr_logged)
+        if save:
+            net.snapshot()
+        if cb.lr != lr_logged:
+            net.lr_t.fill_(cb.lr)
+            if verbose:
+                log(f"\nEpoch {epoch + 1}: ReduceLROnPlateau reducing learning rate to {cb.lr}.")
+        hist.epoch_seconds.append(time.perf_counter() - t0)
+        if verbose:
+            log(f"Epoch {epoch + 1}/{max_epochs} - loss: {loss:.4f} - val_loss: {val:.4f} - "
+                f"learning_rate: {lr_logged:.4e}")
+        if stop:
+            break
+    net.restore_best()
+    return hist

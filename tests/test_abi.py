@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/locator_hip.h declares, ctypes signatures cover them all, and the host-only layout helpers
+agree with the documented swizzle.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from locator_amd import _lib
+
+
+def _header_symbols(repo_root):
+    src = open(os.path.join(repo_root, "include", "locator_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(loc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    lib = _lib.load()
+    names = _header_symbols(repo_root)
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/locator_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.loc_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_lib.Dims) == 24
+    assert C.sizeof(_lib.Layout) == 14 * 8
+
+
+def test_dims_and_layout():
+    d = _lib.make_dims(5830, 256, 10)
+    assert (d.K, d.Kp, d.H, d.Hp, d.L, d.n_pre) == (5830, 5856, 256, 256, 10, 5)
+    lay = _lib.param_layout(d)
+    assert lay.w1 == 0 and lay.gamma == 5856 * 256 and lay.beta == lay.gamma + 5856
+    assert lay.wh == lay.b1 + 256 and lay.bh == lay.wh + 9 * 256 * 256
+    assert lay.n_trainable % 4 == 0 and lay.mov_var == lay.mov_mean + 5856
+    assert lay.n_total == lay.mov_var + 5856
+    d2 = _lib.make_dims(33, 100, 3)
+    assert (d2.Kp, d2.Hp, d2.n_pre) == (64, 128, 1)
+    with pytest.raises(_lib.LocatorHipError):
+        _lib.make_dims(10, 256, 1)          # nlayers < 2 unsupported (documented deviation)
+    with pytest.raises(_lib.LocatorHipError):
+        _lib.make_dims(10, 1024, 4)
+
+
+def test_w1s_index_is_a_bijection_and_matches_mfma_layout():
+    lib = _lib.load()
+    Hp, Kp = 64, 96
+    idx = np.array([[lib.loc_w1s_index(h, k, Hp) for k in range(Kp)] for h in range(Hp)])
+    assert sorted(idx.ravel().tolist()) == list(range(Hp * Kp))
+    # lane l = hi*32 + (k&31), float4 q, component c  <->  unit 8q + 4hi + c of the tile (accumulator rows)
+    for (h, k) in [(0, 0), (5, 3), (37, 40), (63, 95)]:
+        kt, kl, ht, hl = k >> 5, k & 31, h >> 5, h & 31
+        q, hi, c = hl >> 3, (hl >> 2) & 1, hl & 3
+        assert idx[h, k] == ((kt * (Hp // 32) + ht) * 4 + q) * 256 + (hi * 32 + kl) * 4 + c
+    # a (k-tile, unit-tile) block is one contiguous 1024-float run
+    blk = idx[32:64, 32:64]
+    assert blk.min() == (1 * 2 + 1) * 1024 and blk.max() == blk.min() + 1023
