@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be the
+# one already resident when liblocator_hip.so is dlopen'ed, otherwise the library binds /opt/rocm's
+# copy and the process ends up with two HIP runtimes that do not share devices, streams or memory.
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64 first)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocator_hip.so")
 

@@ -3,7 +3,10 @@
 
 Tolerances (all fp32 device arithmetic vs an fp64 oracle; stated per test):
   activations / predictions / losses : 2e-5 absolute on O(1) values
-  one Adam step                      : 2e-6 absolute on weights (updates are <= lr = 1e-3)
+  one Adam step                      : 1e-5 absolute on weights (updates are <= lr = 1e-3), and at most
+                                       0.1 % of a tensor's entries off by more than 2e-6: the entries
+                                       whose gradient is within fp32 round-off of Adam's eps scale
+                                       (|g| ~ 3e-6 at t = 1), where the update is steepest in g
   5 steps                            : 2e-5 absolute on weights, 1e-4 on losses
 """
 import ctypes as C
@@ -166,7 +169,17 @@ def test_one_training_step_matches_oracle(K, width, nlayers, n_b, drop_p):
     assert abs(loss.item() - ref_loss) < 2e-5 * max(1, abs(ref_loss)), (loss.item(), ref_loss)
     got = net.export_params()
     errs = params_err(got, pr)
-    assert max(errs.values()) < 2e-6, errs
+    assert max(errs.values()) < 1e-5, errs
+    for l in range(len(p["W"])):
+        frac = np.mean(np.abs(got["W"][l].astype(np.float64) - pr["W"][l]) > 2e-6)
+        assert frac < 1e-3, (l, frac)
+    # round-off floor: the same step in the fp32 NumPy oracle is not much closer to fp64 than the HIP path
+    p32 = O.cast_params(p, np.float32)
+    m32, v32 = O.zeros_like_trainable(p32), O.zeros_like_trainable(p32)
+    O.train_step(p32, m32, v32, 1, 1e-3, x[idx], y[idx], mask_np[:n_b, :width], drop_p)
+    floor = params_err(p32, pr)
+    for k in errs:
+        assert errs[k] <= 10 * floor[k] + 3e-6, (k, errs[k], floor[k])
     gm, gv = net.export_adam()
     assert max(params_err(gm, m).values()) < 1e-6
     for l in range(len(p["W"])):
