@@ -136,12 +136,13 @@ int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n
                    const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
                    float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
- * dW1 and dxhat are never written to memory. */
+ * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
+ * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel). */
 int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                          const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
                          float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
-                         float* b1, float* m_b1, float* v_b1, const float* alpha_tab, int alpha_tab_len,
-                         const float* lr, const int* t_base, int t_off, int grid, void* stream);
+                         float* b1, float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab,
+                         int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid, void* stream);
 
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,

@@ -55,7 +55,7 @@ SIGNATURES = {
     "loc_l1_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                  C.c_float, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
-                                       vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+                                       vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "loc_dense_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, vp]),
     "loc_dense_backward": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                      C.c_int, vp, vp, C.c_int, vp]),

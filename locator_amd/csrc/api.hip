@@ -56,13 +56,14 @@ extern "C" int loc_param_layout(const loc_dims* d, loc_layout* o) {
 extern "C" int64_t loc_w1s_index(int h, int k, int Hp) { return w1s_index(h, k, Hp / 32); }
 
 struct ws_view {
-    float *bn4, *partial, *acts, *adrop, *dz;
+    float *bn4, *gbs, *partial, *acts, *adrop, *dz;
 };
 static ws_view carve(const loc_dims* d, float* ws) {
     ws_view v;
     const int64_t blk = 32 * (int64_t)d->Hp;
     v.bn4 = ws;
-    v.partial = v.bn4 + 4 * (int64_t)d->Kp;
+    v.gbs = v.bn4 + 4 * (int64_t)d->Kp;
+    v.partial = v.gbs + 4 * (int64_t)d->Kp;
     v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk;
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
@@ -70,7 +71,7 @@ static ws_view carve(const loc_dims* d, float* ws) {
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
     const int64_t blk = 32 * (int64_t)d->Hp;
-    return 4 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk;
+    return 8 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk;
 }
 
 #define TRY(x)                 \
@@ -132,7 +133,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
     TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
                              P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
-                             P + lay.b1, M + lay.b1, V + lay.b1, at, atl, net->lr, net->t_base, t_off,
+                             P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
                              net->l1_bwd_grid, stream));
     if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
     return 0;

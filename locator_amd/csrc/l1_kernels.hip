@@ -11,33 +11,46 @@
 // BN batch statistics (training) — SURVEY.md A.2.  One thread per SNP.
 // out4 = [scale | shift | mean | rstd], scale = gamma*rstd, shift = beta - mean*scale.
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_batch_stats_kernel(const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows,
-                                      int n_b, int K, int Kp, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, float* __restrict__ mov_mean,
-                                      float* __restrict__ mov_var, float* __restrict__ out4) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Kp) return;
-    float scale = 0.f, shift = 0.f, mean = 0.f, rstd = 0.f;
-    if (k < K) {
-        int s = 0, ss = 0;
-        for (int b = 0; b < n_b; ++b) {
-            int x = X[(int64_t)rows[b] * pitch + k];
-            s += x;
-            ss += x * x;
+__global__ __launch_bounds__(128) void bn_batch_stats_kernel(
+    const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mov_mean,
+    float* __restrict__ mov_var, float* __restrict__ out4) {
+    // one thread per 4 consecutive SNPs: a wave reads 256 contiguous bytes of each batch row
+    const int k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k0 >= Kp) return;
+    int s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int b = 0; b < n_b; ++b) {
+        uint32_t v = *reinterpret_cast<const uint32_t*>(X + (int64_t)rows[b] * pitch + k0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int x = (v >> (8 * c)) & 255;
+            s[c] += x;
+            ss[c] += x * x;
         }
-        mean = (float)s / (float)n_b;
-        // biased variance, exact integer numerator: (n*sum(x^2) - sum(x)^2) / n^2
-        float var = (float)(n_b * ss - s * s) / (float)(n_b * n_b);
-        rstd = 1.0f / sqrtf(var + BN_EPS);
-        scale = gamma[k] * rstd;
-        shift = beta[k] - mean * scale;
-        mov_mean[k] = mov_mean[k] * BN_MOMENTUM + mean * (1.0f - BN_MOMENTUM);
-        mov_var[k] = mov_var[k] * BN_MOMENTUM + var * (1.0f - BN_MOMENTUM);
     }
-    out4[k] = scale;
-    out4[Kp + k] = shift;
-    out4[2 * (int64_t)Kp + k] = mean;
-    out4[3 * (int64_t)Kp + k] = rstd;
+    f32x4 o_sc = {0, 0, 0, 0}, o_sh = {0, 0, 0, 0}, o_mu = {0, 0, 0, 0}, o_rs = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        if (k < K) {
+            float mean = (float)s[c] / (float)n_b;
+            // biased variance, exact integer numerator: (n*sum(x^2) - sum(x)^2) / n^2
+            float var = (float)(n_b * ss[c] - s[c] * s[c]) / (float)(n_b * n_b);
+            float rstd = 1.0f / sqrtf(var + BN_EPS);
+            float scale = gamma[k] * rstd;
+            o_sc[c] = scale;
+            o_sh[c] = beta[k] - mean * scale;
+            o_mu[c] = mean;
+            o_rs[c] = rstd;
+            mov_mean[k] = mov_mean[k] * BN_MOMENTUM + mean * (1.0f - BN_MOMENTUM);
+            mov_var[k] = mov_var[k] * BN_MOMENTUM + var * (1.0f - BN_MOMENTUM);
+        }
+    }
+    *reinterpret_cast<f32x4*>(out4 + k0) = o_sc;
+    *reinterpret_cast<f32x4*>(out4 + Kp + k0) = o_sh;
+    *reinterpret_cast<f32x4*>(out4 + 2 * (int64_t)Kp + k0) = o_mu;
+    *reinterpret_cast<f32x4*>(out4 + 3 * (int64_t)Kp + k0) = o_rs;
 }
 
 __global__ void bn_infer_scale_shift_kernel(int K, int Kp, const float* __restrict__ gamma,
@@ -184,52 +197,73 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
 }
 
 // a1[b][h] = ELU(sum_g partial[g][b][h] + b1[h]); optional Dropout on this layer's output.
-__global__ void l1_reduce_kernel(const float* __restrict__ partial, int G, int Hp, const float* __restrict__ b1,
-                                 float* __restrict__ a1, float* __restrict__ a1_drop,
-                                 const uint8_t* __restrict__ mask, float keep_scale) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// Block = 1024 threads = 64 consecutive outputs x 16 groups of partials; fixed summation order.
+__global__ __launch_bounds__(1024) void l1_reduce_kernel(const float* __restrict__ partial, int G, int Hp,
+                                                         const float* __restrict__ b1, float* __restrict__ a1,
+                                                         float* __restrict__ a1_drop,
+                                                         const uint8_t* __restrict__ mask, float keep_scale) {
+    __shared__ float red[16][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
     const int n = 32 * Hp;
-    if (idx >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        s0 += partial[(int64_t)(g + 0) * n + idx];
-        s1 += partial[(int64_t)(g + 1) * n + idx];
-        s2 += partial[(int64_t)(g + 2) * n + idx];
-        s3 += partial[(int64_t)(g + 3) * n + idx];
+    float bias = 0.f, keep = 1.f;
+    if (q == 0) {
+        bias = b1[idx % Hp];
+        if (mask) keep = mask[idx] ? keep_scale : 0.f;
     }
-    for (; g < G; ++g) s0 += partial[(int64_t)g * n + idx];
-    float z = ((s0 + s1) + (s2 + s3)) + b1[idx % Hp];
-    float a = elu_f(z);
-    a1[idx] = a;
-    if (mask) a1_drop[idx] = mask[idx] ? a * keep_scale : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+    int g = q;
+    for (; g + 16 < G; g += 32) {
+        s0 += partial[(int64_t)g * n + idx];
+        s1 += partial[(int64_t)(g + 16) * n + idx];
+    }
+    if (g < G) s0 += partial[(int64_t)g * n + idx];
+    red[q][o] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z += red[j][o];
+        float a = elu_f(z + bias);
+        a1[idx] = a;
+        if (mask) a1_drop[idx] = a * keep;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Layer-1 backward + Adam, one pass over W1/m/v (24 B per weight), nothing else materialised.
-// Block = 256 threads (4 waves), walks k-tiles kt = blockIdx.x, += grid.  Wave w owns unit
-// tiles w, w+4, ...; for each (k-tile, unit-tile) it streams the three 4 KB swizzled runs with
-// 16-byte loads straight into the MFMA accumulator layout:
+//
+// Work unit = one (k-tile, unit-tile) pair = 1024 weights = three contiguous 4 KB runs (W, m, v) in
+// the swizzled layout.  The units, ordered k-tile major, are cut into one contiguous range per WAVE;
+// a wave streams its range with 16-byte loads straight into the MFMA accumulator layout, prefetching
+// the next unit's 12 KB into a second register set while it works on the current one:
 //     dW^T[h][k]  = sum_b dZ[b][h] xhat[b][k]      (A from LDS, B = xhat registers)
 //     dxhat[b][k] += sum_h dZ[b][h] W[h][k]        (A from LDS, B = the weight registers)
-// then Adam in registers and 16-byte stores.  dxhat is reduced over the block's waves in LDS
-// to give dgamma/dbeta (BN on the input has trainable gamma/beta: locator.py:318).
+// then Adam in registers and 16-byte stores.  There is no barrier and no cross-wave traffic in the
+// loop.  dxhat is only needed for BN's trainable gamma/beta (locator.py:318): each wave folds its
+// share into (sum_b dxhat*xn, sum_b dxhat) per SNP and leaves it in `gbs`; a k-tile is touched by at
+// most two waves (ranges are >= NHT units), slot 0 = the wave that did unit-tile 0, slot 1 = the
+// other.  l1_gamma_beta_adam_kernel then adds the two slots in a fixed order and applies Adam.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, float g, float alpha) {
+    m = m + (g - m) * ADAM_C1;
+    v = v + (g * g - v) * ADAM_C2;
+    // v_sqrt_f32 / v_rcp_f32: 1 ulp each, i.e. < 4e-7 relative on an update that is <= lr
+    w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
+}
+
 template <int NHT>
-__global__ __launch_bounds__(256) void l1_bwd_adam_kernel(
+__global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
-    float* __restrict__ v1s, float* __restrict__ gamma, float* __restrict__ beta, float* __restrict__ m_gamma,
-    float* __restrict__ v_gamma, float* __restrict__ m_beta, float* __restrict__ v_beta, float* __restrict__ b1,
-    float* __restrict__ m_b1, float* __restrict__ v_b1, const float* __restrict__ alpha_tab, int alpha_tab_len,
-    const float* __restrict__ lr, const int* __restrict__ t_base, int t_off) {
+    float* __restrict__ v1s, float* __restrict__ gbs, float* __restrict__ b1, float* __restrict__ m_b1,
+    float* __restrict__ v_b1, const float* __restrict__ alpha_tab, int alpha_tab_len,
+    const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
     constexpr int Hp = NHT * 32;
     constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dzl = smem;                    // [32][PZ]
-    float* part = dzl + 32 * PZ;          // [4][16][64]
-    float* red2 = part + 4 * 16 * 64;     // [4][2][64]
-    int* rows_l = reinterpret_cast<int*>(red2 + 4 * 2 * 64);  // [32]
+    float* dzl = smem;                                        // [32][PZ]
+    int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);      // [32]
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
@@ -256,95 +290,126 @@ __global__ __launch_bounds__(256) void l1_bwd_adam_kernel(
         }
     }
 
+    const int gw = blockIdx.x * 4 + w;
+    if (gw >= n_active) return;
+    const int64_t U = (int64_t)nkt * NHT;
+    const int u0 = (int)((int64_t)gw * U / n_active), u1 = (int)((int64_t)(gw + 1) * U / n_active);
+
     const float* sc_p = bn4;
     const float* sh_p = bn4 + Kp;
     const float* mu_p = bn4 + 2 * (int64_t)Kp;
     const float* rs_p = bn4 + 3 * (int64_t)Kp;
 
-    for (int kt = blockIdx.x; kt < nkt; kt += gridDim.x) {
-        const int k = kt * KT + jl;
-        const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k], rs = rs_p[k];
-        float xh[16], xn[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int b = rowmap(r, hi);
-            if (b < n_b) {
-                float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
-                xh[r] = fmaf(xv, sc, sh);
-                xn[r] = (xv - mu) * rs;
-            } else {
-                xh[r] = 0.f;
-                xn[r] = 0.f;
-            }
-        }
-        f32x16 dx = {0};
-        for (int ht = w; ht < NHT; ht += 4) {
-            const int64_t base = ((int64_t)kt * NHT + ht) * 1024;
-            f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
-            f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
-            f32x4* vp = reinterpret_cast<f32x4*>(v1s + base);
-            f32x4 wq[4], mq[4], vq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wq[q] = wp[q * 64 + lane];
-                mq[q] = mp[q * 64 + lane];
-                vq[q] = vp[q * 64 + lane];
-            }
-            // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
-            f32x16 g = {0};
-#pragma unroll
-            for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ht * 32 + jl], xh[s], g);
-            // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                dx = mfma32(dzl[jl * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
-                    adam_update(wv, mv, vv, g[q * 4 + c], alpha);
-                    wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
-                }
-                wp[q * 64 + lane] = wq[q];
-                mp[q * 64 + lane] = mq[q];
-                vp[q * 64 + lane] = vq[q];
-            }
-        }
-        // reduce dxhat over the 4 waves, then dgamma = sum_b dxhat*xn, dbeta = sum_b dxhat
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[(w * 16 + r) * 64 + lane] = dx[r];
-        __syncthreads();
+    float xh[16], xn[16];
+    f32x16 dx = {0};
+    int cur_kt = -1, first_ht = 0;
+
+    auto flush = [&](int kt, int last_ht) {
         float pg = 0.f, pb = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if ((r >> 2) == w) {  // wave-uniform
-                float d = (part[(0 * 16 + r) * 64 + lane] + part[(1 * 16 + r) * 64 + lane]) +
-                          (part[(2 * 16 + r) * 64 + lane] + part[(3 * 16 + r) * 64 + lane]);
-                pg = fmaf(d, xn[r], pg);
-                pb += d;
+            pg = fmaf(dx[r], xn[r], pg);
+            pb += dx[r];
+        }
+        pg += __shfl_xor(pg, 32);
+        pb += __shfl_xor(pb, 32);
+        if (hi == 0) {
+            float* g0 = gbs + (int64_t)kt * 128;   // [slot][2][32]
+            if (first_ht == 0) {
+                g0[jl] = pg; g0[32 + jl] = pb;
+                if (last_ht == NHT - 1) { g0[64 + jl] = 0.f; g0[96 + jl] = 0.f; }
+            } else {
+                g0[64 + jl] = pg; g0[96 + jl] = pb;
             }
         }
-        red2[(w * 2 + 0) * 64 + lane] = pg;
-        red2[(w * 2 + 1) * 64 + lane] = pb;
-        __syncthreads();
-        if (w == 0) {
-            float dg = (red2[(0 * 2 + 0) * 64 + lane] + red2[(1 * 2 + 0) * 64 + lane]) +
-                       (red2[(2 * 2 + 0) * 64 + lane] + red2[(3 * 2 + 0) * 64 + lane]);
-            float db = (red2[(0 * 2 + 1) * 64 + lane] + red2[(1 * 2 + 1) * 64 + lane]) +
-                       (red2[(2 * 2 + 1) * 64 + lane] + red2[(3 * 2 + 1) * 64 + lane]);
-            dg += __shfl_xor(dg, 32);
-            db += __shfl_xor(db, 32);
-            if (hi == 0 && k < K) {
-                float wv = gamma[k], mv = m_gamma[k], vv = v_gamma[k];
-                adam_update(wv, mv, vv, dg, alpha);
-                gamma[k] = wv; m_gamma[k] = mv; v_gamma[k] = vv;
-                wv = beta[k]; mv = m_beta[k]; vv = v_beta[k];
-                adam_update(wv, mv, vv, db, alpha);
-                beta[k] = wv; m_beta[k] = mv; v_beta[k] = vv;
-            }
+    };
+    auto load_unit = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
+        const int64_t base = (int64_t)u * 1024;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w1s + base);
+        const f32x4* mp = reinterpret_cast<const f32x4*>(m1s + base);
+        const f32x4* vp = reinterpret_cast<const f32x4*>(v1s + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wq[q] = wp[q * 64 + lane];
+            mq[q] = mp[q * 64 + lane];
+            vq[q] = vp[q * 64 + lane];
         }
+    };
+    auto step = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4], f32x4 (&wn)[4], f32x4 (&mn)[4],
+                    f32x4 (&vn)[4]) {
+        const int kt = u / NHT, ht = u - kt * NHT;
+        if (kt != cur_kt) {   // wave-uniform
+            if (cur_kt >= 0) flush(cur_kt, NHT - 1);
+            const int k = kt * KT + jl;
+            const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k], rs = rs_p[k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int b = rowmap(r, hi);
+                float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
+                bool ok = b < n_b;
+                xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
+                xn[r] = ok ? (xv - mu) * rs : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+            cur_kt = kt;
+            first_ht = ht;
+        }
+        if (u + 1 < u1) load_unit(u + 1, wn, mn, vn);
+        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
+        f32x16 g = {0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ht * 32 + jl], xh[s], g);
+        // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dx = mfma32(dzl[jl * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
+        const int64_t base = (int64_t)u * 1024;
+        f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
+        f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
+        f32x4* vp = reinterpret_cast<f32x4*>(v1s + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
+                adam_update_fast(wv, mv, vv, g[q * 4 + c], alpha);
+                wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
+            }
+            wp[q * 64 + lane] = wq[q];
+            mp[q * 64 + lane] = mq[q];
+            vp[q * 64 + lane] = vq[q];
+        }
+    };
+
+    if (u0 < u1) {
+        f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
+        load_unit(u0, wA, mA, vA);
+        for (int u = u0; u < u1; u += 2) {
+            step(u, wA, mA, vA, wB, mB, vB);
+            if (u + 1 < u1) step(u + 1, wB, mB, vB, wA, mA, vA);
+        }
+        flush(cur_kt, (u1 - 1) % NHT);
     }
+}
+
+// gamma/beta Adam from the per-wave partial sums left by l1_bwd_adam_kernel (fixed order: slot 0 + slot 1).
+__global__ void l1_gamma_beta_adam_kernel(int K, const float* __restrict__ gbs, float* __restrict__ gamma,
+                                          float* __restrict__ beta, float* __restrict__ m_gamma,
+                                          float* __restrict__ v_gamma, float* __restrict__ m_beta,
+                                          float* __restrict__ v_beta, const float* __restrict__ alpha_tab,
+                                          int alpha_tab_len, const float* __restrict__ lr,
+                                          const int* __restrict__ t_base, int t_off) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
+    const float* g0 = gbs + (int64_t)(k >> 5) * 128 + (k & 31);
+    const float dg = g0[0] + g0[64], db = g0[32] + g0[96];
+    float wv = gamma[k], mv = m_gamma[k], vv = v_gamma[k];
+    adam_update(wv, mv, vv, dg, alpha);
+    gamma[k] = wv; m_gamma[k] = mv; v_gamma[k] = vv;
+    wv = beta[k]; mv = m_beta[k]; vv = v_beta[k];
+    adam_update(wv, mv, vv, db, alpha);
+    beta[k] = wv; m_beta[k] = mv; v_beta[k] = vv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,8 +442,8 @@ extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32
                                   const float* gamma, const float* beta, float* mov_mean, float* mov_var,
                                   float* out4, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_bn_batch_stats: n_b=%d out of 1..32", n_b); return -1; }
-    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, x_pitch,
-                       rows, n_b, K, Kp, gamma, beta, mov_mean, mov_var, out4);
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3((Kp / 4 + 127) / 128), dim3(128), 0, (hipStream_t)stream, X,
+                       x_pitch, rows, n_b, K, Kp, gamma, beta, mov_mean, mov_var, out4);
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -410,8 +475,8 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
     NHT_SWITCH(nht, LAUNCH_FWD)
 #undef LAUNCH_FWD
     LOC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3((32 * d->Hp + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                       grid, d->Hp, b1, a1, a1_drop, mask, keep_scale);
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(32 * d->Hp / 64), dim3(1024), 0, (hipStream_t)stream, partial, grid,
+                       d->Hp, b1, a1, a1_drop, mask, keep_scale);
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -420,23 +485,30 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                                     const loc_dims* d, const float* bn4, const float* dz1, float* w1s, float* m1s,
                                     float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
                                     float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
-                                    const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
-                                    int t_off, int grid, void* stream) {
+                                    float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
+                                    const int* t_base, int t_off, int grid, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..32", n_b); return -1; }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
-    if (grid > nkt) grid = nkt;
-    const size_t lds = ((size_t)32 * (d->Hp + 1) + 4 * 16 * 64 + 4 * 2 * 64 + 32) * sizeof(float);
+    // one contiguous range of >= NHT units per active wave, so a k-tile is split over at most two waves
+    int n_active = grid * 4;
+    if (n_active > nkt) n_active = nkt;
+    grid = (n_active + 3) / 4;
+    const size_t lds = ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float);
 #define LAUNCH_BWD(N)                                                                                          \
     {                                                                                                          \
-        static size_t lds_set = 0;                                                      \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N>, lds); if (rc) return rc; lds_set = lds; }                                                                                     \
+        static size_t lds_set = 0;                                                                             \
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N>, lds); if (rc) return rc; lds_set = lds; } \
         hipLaunchKernelGGL(l1_bwd_adam_kernel<N>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
-                           rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gamma, beta, m_gamma, v_gamma,     \
-                           m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, t_base, t_off);       \
+                           rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
     }
     NHT_SWITCH(nht, LAUNCH_BWD)
 #undef LAUNCH_BWD
+    LOC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
+                       gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,
+                       t_base, t_off);
     LOC_CHECK_LAUNCH();
     return 0;
 }

@@ -74,7 +74,7 @@ class LocatorNet:
         nkt = self.d.Kp // 32
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
-        self.l1_bwd_grid = max(1, min(nkt, 3 * ncu))
+        self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
         self._net = None
         self.init_weights()
 
