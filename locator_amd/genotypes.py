@@ -1,0 +1,315 @@
+"""Genotype ingest and SNP filtering for the locator path, without scikit-allel / zarr / h5py.
+
+Mirrors /root/reference/locator/locator.py:187-281 (load_genotypes, replace_md, filter_snps).
+The reference delegates to scikit-allel (`read_vcf`, `GenotypeArray.count_alleles / is_biallelic /
+to_allele_counts / is_missing`) and zarr; neither is available on the target, so the small subset
+of their behaviour that the path relies on is implemented here on plain NumPy:
+
+  genotypes : int8 array (variants, samples, ploidy=2), -1 = missing allele  (allel.GenotypeArray)
+  count_alleles()[:, a]      number of called alleles equal to a, per variant
+  is_biallelic()             exactly two distinct alleles observed at the variant
+  to_allele_counts()[:,:,1]  per-sample count of allele 1 (missing alleles count as 0)
+  is_missing()               any allele of the call is < 0
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+
+
+# ------------------------------------------------------------------ VCF
+def _parse_gt_fast(fields, n):
+    """All calls are single-digit diploid 'a|b' / 'a/b' with GT the only (or first) FORMAT key."""
+    s = "\t".join(fields)
+    if len(s) != 4 * n - 1:
+        return None
+    arr = np.frombuffer((s + "\t").encode("ascii"), dtype=np.uint8).reshape(n, 4)
+    sep = arr[:, 1]
+    if not np.all((sep == 124) | (sep == 47)) or not np.all(arr[:, 3] == 9):
+        return None
+    out = np.empty((n, 2), np.int8)
+    for j, col in enumerate((0, 2)):
+        c = arr[:, col]
+        digit = (c >= 48) & (c <= 57)
+        if not np.all(digit | (c == 46)):
+            return None
+        out[:, j] = np.where(digit, c.astype(np.int16) - 48, -1).astype(np.int8)
+    return out
+
+
+def _parse_gt_slow(fields, n):
+    out = np.full((n, 2), -1, np.int8)
+    for i, f in enumerate(fields):
+        gt = f.split(":", 1)[0].replace("|", "/").split("/")
+        for j, a in enumerate(gt[:2]):
+            if a != "." and a != "":
+                out[i, j] = int(a)
+        if len(gt) == 1:            # haploid call: second allele stays missing (-1), as allel pads
+            out[i, 1] = -1
+    return out
+
+
+def read_vcf(path):
+    """Subset of allel.read_vcf used by locator.py:195-199: returns dict with 'calldata/GT'
+    (variants, samples, 2) int8, 'samples' (object array of str) and 'variants/POS' (int32)."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    samples, gts, pos = None, [], []
+    with opener(path, "rt") as fh:
+        for line in fh:
+            if line.startswith("##"):
+                continue
+            line = line.rstrip("\n")
+            if line.startswith("#CHROM"):
+                samples = np.array(line.split("\t")[9:], dtype=object)
+                continue
+            if not line:
+                continue
+            f = line.split("\t")
+            n = len(f) - 9
+            fmt = f[8]
+            g = None
+            if fmt == "GT":
+                g = _parse_gt_fast(f[9:], n)
+            if g is None:
+                if fmt.split(":")[0] != "GT":
+                    raise ValueError("VCF FORMAT must start with GT")
+                g = _parse_gt_slow(f[9:], n)
+            gts.append(g)
+            pos.append(int(f[1]))
+    if samples is None:
+        raise ValueError(f"{path}: no #CHROM header line")
+    gt = np.stack(gts, axis=0) if gts else np.zeros((0, len(samples), 2), np.int8)
+    return {"calldata/GT": gt, "samples": samples, "variants/POS": np.asarray(pos, dtype=np.int32)}
+
+
+# ------------------------------------------------------------------ zarr v2 directory store
+class ZarrArray:
+    """Read-only zarr-v2 array in a directory store.  Compressors: none, zlib, gzip.  (Real
+    `allel.vcf_to_zarr` output defaults to blosc, which needs numcodecs: re-encode such stores with
+    `compressor=None` or zlib; see INTEGRATION.md.)  Filters: vlen-utf8 (object string arrays)."""
+
+    def __init__(self, path):
+        self.path = path
+        with open(os.path.join(path, ".zarray")) as fh:
+            meta = json.load(fh)
+        if meta.get("zarr_format") != 2:
+            raise ValueError(f"{path}: only zarr_format 2 is supported")
+        self.shape = tuple(meta["shape"])
+        self.chunks = tuple(meta["chunks"])
+        self.dtype = np.dtype(meta["dtype"])
+        self.order = meta.get("order", "C")
+        self.fill_value = meta.get("fill_value")
+        self.compressor = meta.get("compressor")
+        self.filters = meta.get("filters") or []
+        self.sep = meta.get("dimension_separator", ".")
+        self.ndim = len(self.shape)
+        self.vlen_utf8 = any(f.get("id") == "vlen-utf8" for f in self.filters)
+        if self.compressor is not None and self.compressor.get("id") not in ("zlib", "gzip"):
+            raise ValueError(f"{path}: compressor {self.compressor.get('id')!r} is not supported here "
+                             "(supported: null, zlib, gzip)")
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _decode(self, raw, cshape):
+        if self.compressor is not None:
+            raw = zlib.decompress(raw, 15 + 32)        # auto-detect zlib / gzip framing
+        if self.vlen_utf8:
+            n = struct.unpack_from("<I", raw, 0)[0]
+            out = np.empty(n, dtype=object)
+            off = 4
+            for i in range(n):
+                ln = struct.unpack_from("<I", raw, off)[0]
+                off += 4
+                out[i] = raw[off:off + ln].decode("utf-8")
+                off += ln
+            return out.reshape(cshape, order=self.order)
+        return np.frombuffer(raw, dtype=self.dtype).reshape(cshape, order=self.order)
+
+    def _chunk(self, idx):
+        fn = os.path.join(self.path, self.sep.join(str(i) for i in idx))
+        if not os.path.exists(fn):
+            fill = 0 if self.fill_value is None else self.fill_value
+            return np.full(self.chunks, fill, dtype=object if self.vlen_utf8 else self.dtype)
+        with open(fn, "rb") as fh:
+            return self._decode(fh.read(), self.chunks)
+
+    def __getitem__(self, key):
+        """Supports a[:], a[a:b] and a[a:b, :, :] (slicing on the first axis only)."""
+        if isinstance(key, tuple):
+            if any(k != slice(None) for k in key[1:]):
+                raise IndexError("ZarrArray: only the first axis can be sliced")
+            key = key[0]
+        if not isinstance(key, slice):
+            raise IndexError("ZarrArray: use a slice")
+        start, stop, step = key.indices(self.shape[0])
+        if step != 1:
+            raise IndexError("ZarrArray: step must be 1")
+        n0 = max(stop - start, 0)
+        out = np.empty((n0,) + self.shape[1:], dtype=object if self.vlen_utf8 else self.dtype)
+        if n0 == 0:
+            return out
+        c0 = self.chunks[0]
+        grid = [range((s + c - 1) // c) for s, c in zip(self.shape[1:], self.chunks[1:])]
+        for ci in range(start // c0, (stop - 1) // c0 + 1):
+            lo, hi = max(start, ci * c0), min(stop, (ci + 1) * c0)
+
+            def rec(prefix, dims):
+                if not dims:
+                    ch = self._chunk((ci,) + tuple(prefix))
+                    sl = [slice(lo - ci * c0, hi - ci * c0)]
+                    dst = [slice(lo - start, hi - start)]
+                    for ax, j in enumerate(prefix):
+                        c = self.chunks[ax + 1]
+                        a, b = j * c, min((j + 1) * c, self.shape[ax + 1])
+                        sl.append(slice(0, b - a))
+                        dst.append(slice(a, b))
+                    out[tuple(dst)] = ch[tuple(sl)]
+                    return
+                for j in dims[0]:
+                    rec(prefix + [j], dims[1:])
+
+            rec([], grid)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[:]
+        return a.astype(dtype) if dtype is not None else a
+
+
+class ZarrGroup:
+    """`zarr.open_group(path, mode='r')` stand-in: group['calldata/GT'] -> ZarrArray."""
+
+    def __init__(self, path):
+        if not os.path.isdir(path):
+            raise FileNotFoundError(path)
+        self.path = path
+
+    def __getitem__(self, key):
+        p = os.path.join(self.path, *key.split("/"))
+        if os.path.exists(os.path.join(p, ".zarray")):
+            return ZarrArray(p)
+        if os.path.isdir(p):
+            return ZarrGroup(p)
+        raise KeyError(key)
+
+
+def open_group(path, mode="r"):
+    return ZarrGroup(path)
+
+
+def write_zarr_array(path, arr, chunks, compressor=None):
+    """Minimal zarr-v2 writer (uncompressed or zlib) used to build synthetic stores (config 4)."""
+    arr = np.asarray(arr)
+    os.makedirs(path, exist_ok=True)
+    chunks = tuple(int(min(c, s)) if s else 1 for c, s in zip(chunks, arr.shape))
+    meta = {"zarr_format": 2, "shape": list(arr.shape), "chunks": list(chunks), "dtype": arr.dtype.str,
+            "compressor": ({"id": "zlib", "level": 1} if compressor == "zlib" else None), "fill_value": 0,
+            "order": "C", "filters": None}
+    with open(os.path.join(path, ".zarray"), "w") as fh:
+        json.dump(meta, fh)
+    ranges = [range((s + c - 1) // c) for s, c in zip(arr.shape, chunks)]
+    import itertools
+    for idx in itertools.product(*ranges):
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, arr.shape))
+        block = np.zeros(chunks, arr.dtype)
+        block[tuple(slice(0, s.stop - s.start) for s in sl)] = arr[sl]
+        raw = block.tobytes()
+        if compressor == "zlib":
+            raw = zlib.compress(raw, 1)
+        with open(os.path.join(path, ".".join(map(str, idx))), "wb") as fh:
+            fh.write(raw)
+
+
+def write_callset_zarr(path, gt, pos, samples, chunk_variants=65536, compressor=None):
+    """Synthetic `allel.vcf_to_zarr`-shaped store: calldata/GT, variants/POS, samples."""
+    os.makedirs(path, exist_ok=True)
+    for g in ("", "calldata", "variants"):
+        os.makedirs(os.path.join(path, g), exist_ok=True)
+        with open(os.path.join(path, g, ".zgroup"), "w") as fh:
+            json.dump({"zarr_format": 2}, fh)
+    gt = np.asarray(gt, dtype=np.int8)
+    write_zarr_array(os.path.join(path, "calldata", "GT"), gt, (chunk_variants, gt.shape[1], 2), compressor)
+    write_zarr_array(os.path.join(path, "variants", "POS"), np.asarray(pos, np.int32), (chunk_variants,), compressor)
+    s = np.asarray(samples)
+    write_zarr_array(os.path.join(path, "samples"), s.astype("U"), (len(s),), None)
+
+
+# ------------------------------------------------------------------ tab-delimited count matrix
+def read_matrix(path):
+    """locator.py:200-227: first column 'sampleID', then one column per site holding 0/1/2 counts.
+    The reference turns count c into haplotypes (1 if c>=1, 1 if c==2) and re-counts; other values
+    contribute nothing.  Returns the equivalent (variants, samples, 2) int8 genotype array."""
+    import pandas as pd
+    gmat = pd.read_csv(path, sep="\t")
+    samples = np.array(gmat["sampleID"])
+    g = np.array(gmat.drop(labels="sampleID", axis=1), dtype="int8")      # samples x sites
+    h1 = ((g == 1) | (g == 2)).astype(np.int8)
+    h2 = (g == 2).astype(np.int8)
+    gt = np.stack([h1.T, h2.T], axis=2)
+    return gt, samples
+
+
+# ------------------------------------------------------------------ allel.GenotypeArray subset
+def count_alleles(gt, max_allele=None):
+    """(variants, max_allele+1) int32 counts of called alleles; max_allele defaults to the data's max."""
+    if max_allele is None:
+        max_allele = int(gt.max()) if gt.size else 0
+    max_allele = max(max_allele, 0)
+    out = np.zeros((gt.shape[0], max_allele + 1), np.int32)
+    flat = gt.reshape(gt.shape[0], -1)
+    for a in range(max_allele + 1):
+        out[:, a] = (flat == a).sum(axis=1)
+    return out
+
+
+def is_biallelic(ac):
+    return (ac > 0).sum(axis=1) == 2
+
+
+def to_allele_counts_1(gt):
+    """to_allele_counts()[:, :, 1]: per-sample number of allele-1 copies; int8 (variants, samples)."""
+    return (gt == 1).sum(axis=2).astype(np.int8)
+
+
+def is_missing(gt):
+    return (gt < 0).any(axis=2)
+
+
+def replace_md(gt, rng=np.random):
+    """locator.py:251-262: impute missing calls with Binomial(2, allele-1 frequency of the site), drawing
+    from the global legacy NumPy stream once per missing call in variant-major order."""
+    dc = count_alleles(gt, max(int(gt.max()), 1))[:, 1]
+    ac = to_allele_counts_1(gt)
+    missingness = is_missing(gt)
+    ninds = (~missingness).sum(axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        af = dc / (2 * ninds)
+    for i, j in np.argwhere(missingness):
+        ac[i, j] = rng.binomial(2, af[i])
+    return ac
+
+
+def filter_snps(gt, min_mac=2, max_snps=None, impute_missing=False, rng=np.random, verbose=True):
+    """locator.py:265-281: biallelic sites -> allele-1 count >= min_mac (skipped when min_mac == 1) ->
+    allele-1 count matrix (sites x samples) -> optional random subset of max_SNPs sites.
+    Quirks kept: the count filtered on is allele 1's, not the minor allele's; monomorphic
+    sites never pass (Q8)."""
+    if verbose:
+        print("filtering SNPs")
+    tmp = count_alleles(gt)
+    gt = gt[is_biallelic(tmp)]
+    if not min_mac == 1:
+        derived = count_alleles(gt, max(int(gt.max()) if gt.size else 1, 1))[:, 1]
+        gt = gt[derived >= min_mac]
+    ac = replace_md(gt, rng) if impute_missing else to_allele_counts_1(gt)
+    if max_snps is not None:
+        ac = ac[rng.choice(range(ac.shape[0]), max_snps, replace=False), :]
+    if verbose:
+        print("running on " + str(len(ac)) + " genotypes after filtering\n\n\n")
+    return ac

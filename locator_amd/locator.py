@@ -1,0 +1,497 @@
+#!/usr/bin/env python3
+"""`locator` command line on MI355X — drop-in for /root/reference/locator/locator.py.
+
+Same flags (locator.py:12-167), same pipeline (main, locator.py:487-749), same output files
+(`{out}_predlocs.txt`, `{out}_history.txt`, `{out}_params.json`, `{out}_fitplot.pdf`), but the
+Keras model / fit / predict are replaced by hand-written HIP kernels for gfx950 driven through
+liblocator_hip.so, and the --windows / --bootstrap replicate loops are sharded over the GPUs of the
+node (one model per GPU, no collectives).
+
+Function names and signatures follow the reference so that its call sites read the same:
+  load_genotypes, sort_samples, replace_md, filter_snps, normalize_locs, split_train_test,
+  load_network, load_callbacks, train_network, predict_locs, plot_history, main.
+
+Deliberate, documented deviations:
+  * flags are parsed in main(), not at import; params.json is therefore written once, not twice
+    (same content);
+  * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
+    h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
+  * --batch_size is limited to 32 rows (the reference default) and --nlayers must be >= 2;
+  * extra flags --gpus / --no_graph / --net_seed (recorded at the end of params.json).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import genotypes as G
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="locator")
+    p.add_argument("--vcf", help="VCF (optionally gzipped) holding the SNPs of every sample")
+    p.add_argument("--zarr", help="zarr-v2 directory store with calldata/GT, variants/POS and samples")
+    p.add_argument("--matrix", help="tab-delimited table: a 'sampleID' column followed by one 0/1/2 "
+                                    "allele-count column per site")
+    p.add_argument("--sample_data", help="tab-delimited table with columns sampleID, x, y; x and y are NA "
+                                         "for the samples whose location is to be predicted")
+    p.add_argument("--train_split", default=0.9, type=float,
+                   help="fraction of located samples used for training (default 0.9)")
+    p.add_argument("--windows", default=False, action="store_true",
+                   help="fit one model per genomic window of a single chromosome (needs --zarr)")
+    p.add_argument("--window_start", default=0, help="first window start (default 0)")
+    p.add_argument("--window_stop", default=None, help="end of the last window (default: largest position)")
+    p.add_argument("--window_size", default=5e5, help="window length in bp (default 500000)")
+    p.add_argument("--bootstrap", default=False, action="store_true",
+                   help="refit on SNP-resampled copies of the data (--nboots replicates after a full fit)")
+    p.add_argument("--jacknife", default=False, action="store_true",
+                   help="quick uncertainty heuristic: re-predict with a fraction of SNPs redrawn")
+    p.add_argument("--jacknife_prop", default=0.05, type=float,
+                   help="fraction of SNPs redrawn per jacknife replicate (default 0.05)")
+    p.add_argument("--nboots", default=50, type=int, help="number of bootstrap / jacknife replicates (default 50)")
+    p.add_argument("--batch_size", default=32, type=int, help="minibatch size (default 32; at most 32 here)")
+    p.add_argument("--max_epochs", default=5000, type=int, help="upper bound on training epochs (default 5000)")
+    p.add_argument("--patience", type=int, default=100,
+                   help="epochs without validation improvement before training stops (default 100)")
+    p.add_argument("--min_mac", default=2, type=int, help="minimum allele-1 count for a SNP to be kept (default 2)")
+    p.add_argument("--max_SNPs", default=None, type=int, help="use a random subset of this many SNPs (default all)")
+    p.add_argument("--impute_missing", default=False, action="store_true",
+                   help="draw missing calls from Binomial(2, site frequency) instead of counting them as 0")
+    p.add_argument("--dropout_prop", default=0.25, type=float, help="dropout rate of the middle layer (default 0.25)")
+    p.add_argument("--nlayers", default=10, type=int, help="number of hidden layers (default 10)")
+    p.add_argument("--width", default=256, type=int, help="units per hidden layer (default 256)")
+    p.add_argument("--out", help="stem of every output file")
+    p.add_argument("--seed", default=None, type=int, help="NumPy seed for the train/validation split and SNP draws")
+    p.add_argument("--gpu_number", default=None, type=str, help="restrict the run to this GPU index")
+    p.add_argument("--plot_history", default=True, type=bool, help="write {out}_fitplot.pdf (default True)")
+    p.add_argument("--keep_weights", default=False, action="store_true", help="keep the best weights on disk")
+    p.add_argument("--load_params", default=None, type=str,
+                   help="path of a _params.json from an earlier run; replaces every command-line value")
+    p.add_argument("--keras_verbose", default=1, type=int,
+                   help="0 silent, 1 or 2 one line per epoch (default 1)")
+    # --- additions of this implementation (kept last so the reference's keys keep their order)
+    p.add_argument("--gpus", default=None, type=int,
+                   help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
+    p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
+    p.add_argument("--net_seed", default=None, type=int,
+                   help="seed of weight init / shuffling / dropout (the reference leaves these unseeded); "
+                        "default: --seed, else entropy")
+    return p
+
+
+args = None          # module-level namespace, as in the reference (locator.py:167)
+
+
+def _setup(argv=None):
+    """locator.py:169-184 / :490-505 — seed NumPy, pick the GPU, --load_params, write params.json."""
+    global args
+    args = build_parser().parse_args(argv)
+    if args.seed is not None:
+        np.random.seed(args.seed)
+    if args.gpu_number is not None:
+        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu_number
+        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu_number
+    if args.load_params is not None:
+        defaults = vars(build_parser().parse_args([]))
+        with open(args.load_params, "r") as f:
+            loaded = json.load(f)
+        defaults.update(loaded)                # a reference-written json lacks the added keys
+        args.__dict__ = defaults
+    with open(args.out + "_params.json", "w") as f:
+        json.dump(args.__dict__, f, indent=2)
+    if args.net_seed is None:
+        args._net_seed = args.seed if args.seed is not None else int.from_bytes(os.urandom(4), "little")
+    else:
+        args._net_seed = args.net_seed
+    return args
+
+
+# ------------------------------------------------------------------ ingest (locator.py:187-308)
+def load_genotypes():
+    if args.zarr is not None:
+        print("reading zarr")
+        callset = G.open_group(args.zarr, mode="r")
+        genotypes = np.asarray(callset["calldata/GT"][:], dtype=np.int8)
+        samples = np.asarray(callset["samples"][:])
+    elif args.vcf is not None:
+        print("reading VCF")
+        vcf = G.read_vcf(args.vcf)
+        genotypes = vcf["calldata/GT"]
+        samples = vcf["samples"]
+    elif args.matrix is not None:
+        genotypes, samples = G.read_matrix(args.matrix)
+    else:
+        raise SystemExit("one of --zarr, --vcf or --matrix is required")
+    return genotypes, samples
+
+
+def sort_samples(samples, genotypes):
+    import pandas as pd
+    sample_data = pd.read_csv(args.sample_data, sep="\t")
+    sample_data["sampleID2"] = sample_data["sampleID"]
+    sample_data.set_index("sampleID", inplace=True)
+    samples = np.asarray(samples).astype("str")
+    sample_data = sample_data.reindex(np.array(samples))
+    if not all([sample_data["sampleID2"].iloc[x] == samples[x] for x in range(len(samples))]):
+        print("sample ordering failed! Check that sample IDs match the VCF.")
+        sys.exit()
+    locs = np.array(sample_data[["x", "y"]])
+    print("loaded " + str(np.shape(genotypes)) + " genotypes\n\n")
+    return sample_data, locs
+
+
+def replace_md(genotypes):
+    print("imputing missing data")
+    return G.replace_md(genotypes)
+
+
+def filter_snps(genotypes):
+    return G.filter_snps(genotypes, min_mac=args.min_mac, max_snps=args.max_SNPs,
+                         impute_missing=args.impute_missing)
+
+
+def normalize_locs(locs):
+    meanlong = np.nanmean(locs[:, 0])
+    sdlong = np.nanstd(locs[:, 0])
+    meanlat = np.nanmean(locs[:, 1])
+    sdlat = np.nanstd(locs[:, 1])
+    locs = np.stack([(locs[:, 0] - meanlong) / sdlong, (locs[:, 1] - meanlat) / sdlat], axis=1)
+    return meanlong, sdlong, meanlat, sdlat, locs
+
+
+def split_indices(locs, train_split):
+    """The index part of split_train_test (locator.py:296-302): one np.random.choice from the global stream."""
+    train = np.argwhere(~np.isnan(locs[:, 0]))[:, 0]
+    known = set(train.tolist())
+    pred = np.array([x for x in range(len(locs)) if x not in known], dtype=np.int64)
+    test = np.random.choice(train, round((1 - train_split) * len(train)), replace=False)
+    tset = set(test.tolist())
+    train = np.array([x for x in train if x not in tset])
+    return train, test, pred
+
+
+def split_train_test(ac, locs):
+    train, test, pred = split_indices(locs, args.train_split)
+    traingen = np.transpose(ac[:, train])
+    trainlocs = locs[train]
+    testgen = np.transpose(ac[:, test])
+    testlocs = locs[test]
+    predgen = np.transpose(ac[:, pred]) if len(pred) else np.zeros((0, ac.shape[0]), ac.dtype)
+    return train, test, traingen, testgen, trainlocs, testlocs, pred, predgen
+
+
+# ------------------------------------------------------------------ model (locator.py:311-470)
+class DeviceRows:
+    """Rows [start, start+n) of a genotype matrix already resident in HBM; stands in for the NumPy
+    traingen / testgen / predgen of the reference so replicates need no host copies."""
+
+    def __init__(self, X, start, n, K):
+        self.X, self.start, self.n = X, int(start), int(n)
+        self.shape = (int(n), int(K))
+
+
+class Model:
+    """What `load_network` returns in place of a compiled keras.Sequential: the hyper-parameters now,
+    the device-resident LocatorNet once train_network has seen the data."""
+
+    def __init__(self, n_snps, dropout_prop, width, nlayers, seed, replicate=0, device="cuda:0"):
+        self.n_snps, self.dropout_prop, self.width, self.nlayers = n_snps, dropout_prop, width, nlayers
+        self.seed, self.replicate, self.device = seed, replicate, device
+        self.net = None
+        self.n_train = self.n_val = 0
+        self._val_key = None
+
+    def _build(self, X, Y):
+        from .net import LocatorNet
+        self.net = LocatorNet(X, Y, self.n_snps, self.width, self.nlayers, self.dropout_prop, seed=self.seed,
+                              replicate=self.replicate, device=self.device)
+        return self.net
+
+    def predict(self, gen):
+        """model.predict(x) (locator.py:414, :441): inference-mode forward, float32 (n, 2)."""
+        import torch
+        from .net import upload_genotypes
+        n = gen.shape[0]
+        if n == 0:
+            return np.zeros((0, 2), np.float32)
+        net = self.net
+        keepX = net.X
+        if isinstance(gen, DeviceRows):
+            net.X, start = gen.X, gen.start
+        else:
+            net.X, start = upload_genotypes(np.asarray(gen), self.device), 0
+        net.cnet()
+        rows = torch.arange(start, start + n, dtype=torch.int32, device=self.device)
+        yhat = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+        net.predict_rows(rows, n, yhat)
+        torch.cuda.synchronize()
+        net.X = keepX
+        net.cnet()
+        return yhat.cpu().numpy()
+
+    def weights_dict(self):
+        return self.net.export_params()
+
+
+def load_network(traingen, dropout_prop, replicate=0, device="cuda:0"):
+    # the reference ignores its dropout_prop argument and reads args.dropout_prop
+    return Model(traingen.shape[1], args.dropout_prop, args.width, args.nlayers, args._net_seed, replicate, device)
+
+
+def _weights_path(boot):
+    if args.bootstrap or args.jacknife:
+        return args.out + "_boot" + str(boot) + ".weights.npz"
+    return args.out + ".weights.npz"
+
+
+def load_callbacks(boot):
+    """locator.py:330-362.  The three Keras callbacks are state machines on val_loss; they are
+    instantiated inside train.fit.  Returned here as their configuration, in the reference's order."""
+    checkpointer = {"callback": "ModelCheckpoint", "filepath": _weights_path(boot), "save_best_only": True,
+                    "save_weights_only": True, "monitor": "val_loss"}
+    earlystop = {"callback": "EarlyStopping", "monitor": "val_loss", "min_delta": 0, "patience": args.patience}
+    reducelr = {"callback": "ReduceLROnPlateau", "monitor": "val_loss", "factor": 0.5,
+                "patience": int(args.patience / 6), "min_delta": 0, "cooldown": 0, "min_lr": 0}
+    return checkpointer, earlystop, reducelr
+
+
+def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot=0):
+    import torch
+    from .net import upload_genotypes
+    from .train import fit
+    start = time.time()
+    ntr, nva = traingen.shape[0], testgen.shape[0]
+    if isinstance(traingen, DeviceRows):
+        assert isinstance(testgen, DeviceRows) and testgen.X is traingen.X
+        X, tr0, va0 = traingen.X, traingen.start, testgen.start
+    else:
+        X = upload_genotypes(np.concatenate([np.asarray(traingen), np.asarray(testgen)], axis=0), model.device)
+        tr0, va0 = 0, ntr
+    yh = np.zeros((X.shape[0], 2), np.float32)
+    yh[tr0:tr0 + ntr] = trainlocs
+    yh[va0:va0 + nva] = testlocs
+    Y = torch.from_numpy(yh).to(model.device)
+    model._build(X, Y)
+    model.n_train, model.n_val = ntr, nva
+    history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
+                  max_epochs=args.max_epochs, patience=args.patience, use_graph=not args.no_graph,
+                  verbose=args.keras_verbose)
+    if args.keep_weights:          # reference: Keras HDF5 kept on disk (locator.py:332-348, :379-388)
+        w = model.weights_dict()
+        flat = {"gamma": w["gamma"], "beta": w["beta"], "moving_mean": w["mov_mean"], "moving_variance": w["mov_var"]}
+        for i, (k, b) in enumerate(zip(w["W"], w["b"])):
+            flat[f"dense_{i}_kernel"], flat[f"dense_{i}_bias"] = k, b
+        np.savez(callbacks[0]["filepath"], **flat)
+    elapsed = time.time() - start
+    print("run time " + str(elapsed / 60) + " minutes")
+    return history, model
+
+
+def predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
+                 boot=0, verbose=True):
+    import pandas as pd
+    from scipy import spatial
+    if verbose:
+        print("predicting locations...")
+    prediction = model.predict(predgen)
+    prediction = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in prediction]).reshape(-1, 2)
+    predout = pd.DataFrame(prediction)
+    predout.columns = ["x", "y"]
+    predout["sampleID"] = np.asarray(samples)[pred] if len(pred) else []
+    if args.bootstrap or args.jacknife:
+        outfile = args.out + "_boot" + str(boot) + "_predlocs.txt"
+    elif args.windows:
+        # the reference appends the *flag* window to an --out that already carries the real window
+        window_start = int(args.window_start)
+        window_size = int(args.window_size)
+        outfile = f"{args.out}_{window_start}-{window_start + window_size - 1}_predlocs.txt"
+    else:
+        outfile = args.out + "_predlocs.txt"
+    predout.to_csv(outfile, index=False)
+
+    testlocs2 = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in testlocs])
+    p2 = model.predict(testgen)
+    p2 = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in p2])
+    r2_long = np.corrcoef(p2[:, 0], testlocs2[:, 0])[0][1] ** 2
+    r2_lat = np.corrcoef(p2[:, 1], testlocs2[:, 1])[0][1] ** 2
+    dists = [spatial.distance.euclidean(p2[x, :], testlocs2[x, :]) for x in range(len(p2))]
+    mean_dist = np.mean(dists)
+    median_dist = np.median(dists)
+    if verbose:
+        print("R2(x)=" + str(r2_long) + "\nR2(y)=" + str(r2_lat) + "\n" + "mean validation error " + str(mean_dist)
+              + "\n" + "median validation error " + str(median_dist) + "\n")
+    hist = pd.DataFrame(history.history)
+    hist.to_csv(args.out + "_history.txt", sep="\t", index=False)
+    return dists
+
+
+def plot_history(history, dists):
+    if args.plot_history:
+        import matplotlib
+        matplotlib.use("agg")
+        from matplotlib import pyplot as plt
+        fig = plt.figure(figsize=(4, 1.5), dpi=200)
+        plt.rcParams.update({"font.size": 7})
+        ax1 = fig.add_axes([0, 0, 0.4, 1])
+        ax1.plot(history.history["val_loss"][3:], "-", color="black", lw=0.5)
+        ax1.set_xlabel("Validation Loss")
+        ax2 = fig.add_axes([0.55, 0, 0.4, 1])
+        ax2.plot(history.history["loss"][3:], "-", color="black", lw=0.5)
+        ax2.set_xlabel("Training Loss")
+        fig.savefig(args.out + "_fitplot.pdf", bbox_inches="tight")
+        plt.close(fig)
+
+
+# ------------------------------------------------------------------ replicate units (windows / bootstrap)
+_BASE_CACHE = {}      # per worker process: the shared genotype rows, uploaded once per device
+
+
+def _fit_unit(unit, device="cuda:0"):
+    """One replicate fit + predict on `device` — the body of the reference's window / bootstrap loops
+    (locator.py:546-571, :656-676).  `unit` carries everything that depended on the NumPy stream.
+    The unit's train / validation / prediction rows are uploaded once as one uint8 matrix; a
+    bootstrap unit resamples its SNP columns on the device (loc_gather_columns) instead of the
+    reference's three host fancy-index copies (locator.py:651-653)."""
+    global args
+    from .net import gather_columns, upload_genotypes
+    args = unit["args"]
+    t1 = time.time()
+    tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
+    ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
+    key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
+    X = _BASE_CACHE.get(key) if key else None
+    if X is None:
+        X = upload_genotypes(np.concatenate([np.asarray(tg), np.asarray(vg), np.asarray(pg).reshape(npr, K)], axis=0),
+                             device)
+        if key:
+            _BASE_CACHE.clear()
+            _BASE_CACHE[key] = X
+    if unit.get("site_order") is not None:
+        X = gather_columns(X, unit["site_order"], K)
+    traingen, testgen = DeviceRows(X, 0, ntr, K), DeviceRows(X, ntr, nva, K)
+    predgen = DeviceRows(X, ntr + nva, npr, K)
+    model = load_network(traingen, args.dropout_prop, replicate=unit["replicate"], device=device)
+    callbacks = load_callbacks(unit["boot"])
+    history, model = train_network(model, traingen, testgen, unit["trainlocs"], unit["testlocs"], callbacks,
+                                   unit["boot"])
+    original_out = args.out
+    args.out = unit["out"]
+    dists = predict_locs(model, predgen, unit["sdlong"], unit["meanlong"], unit["sdlat"], unit["meanlat"],
+                         unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
+    args.out = original_out
+    return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t1}
+
+
+def _window_units(samples):
+    """Host prologue of the window loop, in reference order (locator.py:519-545): everything that reads
+    the zarr store or advances the global NumPy stream happens here, sequentially."""
+    callset = G.open_group(args.zarr, mode="r")
+    gt = callset["calldata/GT"]
+    positions = np.array(callset["variants/POS"][:])
+    start = int(args.window_start)
+    stop = np.max(positions) if args.window_stop is None else int(args.window_stop)
+    size = int(args.window_size)
+    units = []
+    for n, i in enumerate(np.arange(start, stop, size)):
+        print(f"\nProcessing window {i}-{i + size}")
+        mask = np.logical_and(positions >= i, positions < i + size)
+        a = np.min(np.argwhere(mask))
+        b = np.max(np.argwhere(mask))
+        print(f"SNPs {a}-{b}")
+        genotypes = np.asarray(gt[a:b, :, :], dtype=np.int8)       # excludes SNP b, as the reference does (Q4)
+        sample_data, locs = sort_samples(samples, genotypes)
+        meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+        ac = filter_snps(genotypes)
+        train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
+        units.append(dict(name=f"window {i}-{i + size - 1}", replicate=n, boot=None, out=f"{args.out}_{i}-{i + size - 1}",
+                          traingen=np.ascontiguousarray(traingen), testgen=np.ascontiguousarray(testgen),
+                          predgen=np.ascontiguousarray(predgen), trainlocs=trainlocs, testlocs=testlocs, pred=pred,
+                          samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat))
+    return units
+
+
+def _bootstrap_units(n_sites):
+    """FULL fit + nboots resamples; the reseed / site_order chain is drawn here, sequentially and in
+    reference order (locator.py:635-650).  Units are small: the genotype rows travel once as `shared`."""
+    units = [dict(name="boot FULL", replicate=0, boot="FULL", site_order=None, cache_base=True)]
+    for boot in range(args.nboots):
+        np.random.seed(np.random.choice(range(int(1e6)), 1))
+        site_order = np.random.choice(n_sites, n_sites, replace=True).astype(np.int32)
+        units.append(dict(name=f"boot {boot}", replicate=boot + 1, boot=boot, site_order=site_order,
+                          cache_base=True))
+    return units
+
+
+# ------------------------------------------------------------------ main (locator.py:487-749)
+def main(argv=None):
+    _setup(argv)
+    from . import replicates
+
+    genotypes, samples = load_genotypes()
+    sample_data, locs = sort_samples(samples, genotypes)
+    meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+    ac = filter_snps(genotypes)
+    train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
+
+    if args.windows:
+        units = _window_units(samples)
+        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus)
+        for r in results:                       # fitplot is overwritten per window in the reference
+            print(f"{r['name']}: run time {r['seconds'] / 60:.2f} minutes")
+        if results and args.plot_history:
+            plot_history(_H(results[-1]["history"]), results[-1]["dists"])
+    elif not args.bootstrap and not args.jacknife:
+        unit = dict(name="single", replicate=0, boot=0, out=args.out, traingen=traingen, testgen=testgen,
+                    predgen=predgen, trainlocs=trainlocs, testlocs=testlocs, pred=pred, samples=samples,
+                    sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, args=args)
+        r = _fit_unit(unit)
+        if "error" in r:
+            raise SystemExit(r["error"])
+        plot_history(_H(r["history"]), r["dists"])
+    elif args.bootstrap:
+        units = _bootstrap_units(traingen.shape[1])
+        shared = dict(traingen=np.ascontiguousarray(traingen), testgen=np.ascontiguousarray(testgen),
+                      predgen=np.ascontiguousarray(predgen), trainlocs=trainlocs, testlocs=testlocs, pred=pred,
+                      samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, out=args.out)
+        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, shared=shared)
+        # {out}_history.txt / fitplot are overwritten by every replicate in the reference: last one wins
+        if results:
+            import pandas as pd
+            pd.DataFrame(results[-1]["history"]).to_csv(args.out + "_history.txt", sep="\t", index=False)
+            if args.plot_history:
+                plot_history(_H(results[-1]["history"]), results[-1]["dists"])
+    elif args.jacknife:
+        boot = "FULL"
+        model = load_network(traingen, args.dropout_prop)
+        callbacks = load_callbacks(boot)
+        start = time.time()
+        history, model = train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot)
+        dists = predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen,
+                             history, boot)
+        plot_history(history, dists)
+        print("run time " + str((time.time() - start) / 60) + " minutes")
+        print("starting jacknife resampling")
+        af = ac.sum(axis=1) / (ac.shape[1] * 2)
+        for boot in range(args.nboots):
+            pg = copy.deepcopy(np.asarray(predgen))
+            sites_to_remove = np.random.choice(pg.shape[1], int(pg.shape[1] * args.jacknife_prop), replace=False)
+            for i in sites_to_remove:
+                pg[:, i] = np.random.binomial(2, af[i], pg.shape[0])
+            predict_locs(model, pg, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
+                         boot, verbose=False)
+    return 0
+
+
+class _H:
+    def __init__(self, history):
+        self.history = history
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,123 @@
+"""Sharding of independent replicate fits (--windows, --bootstrap) over the GPUs of one node.
+
+Reference: the window loop (/root/reference/locator/locator.py:531-583) and the bootstrap loop
+(:635-681) are strictly sequential `for` loops on one device.  The fits are independent once the
+parts that advance the global NumPy stream (splits, reseeds, site orders) have been drawn, so here
+the parent draws those sequentially in reference order and the fits run one model per GPU.
+
+  * no collective on the data path: a unit's inputs go to exactly one worker, its outputs are the
+    files it writes plus a small result record;
+  * per-unit randomness (init, shuffles, dropout) is keyed by the unit's replicate index, never by
+    the worker, so 1-GPU and 8-GPU runs write identical files;
+  * dynamic queue (run_units) because early stopping makes unit durations vary several-fold; a
+    static round-robin (shard_static / run_units_distributed) is provided for launches that are
+    already one-process-per-GPU (torch.distributed.run), where ranks cannot share a queue;
+  * a failed unit is reported and does not stop its siblings.
+"""
+from __future__ import annotations
+
+import traceback
+
+
+def shard_static(n_units, rank, world):
+    """Unit indices of `rank` under round-robin assignment."""
+    return list(range(rank, n_units, world))
+
+
+def _run_one(fit_fn, unit, shared, args, device):
+    u = dict(shared or {})
+    u.update(unit)
+    u["args"] = args
+    try:
+        return fit_fn(u, device=device)
+    except Exception as e:                                   # noqa: BLE001 — reported, siblings continue
+        return {"name": unit.get("name", "?"), "error": f"{type(e).__name__}: {e}",
+                "traceback": traceback.format_exc()}
+
+
+def _worker(gpu, fit_fn, shared, args, prepare, tasks, results):
+    import torch
+    torch.cuda.set_device(gpu)
+    device = f"cuda:{gpu}"
+    while True:
+        item = tasks.get()
+        if item is None:
+            break
+        idx, unit = item
+        if prepare is not None:
+            unit = prepare(unit)
+        r = _run_one(fit_fn, unit, shared, args, device)
+        r["unit_index"], r["gpu"] = idx, gpu
+        results.put(r)
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print):
+    """Run every unit once; returns the result records in unit order.
+
+    units    list of dicts (small per-unit data; window units carry their own genotype slices)
+    shared   dict of data common to all units (sent to each worker once)
+    prepare  optional per-unit hook run in the worker before fit_fn (e.g. column resampling)"""
+    n_vis = visible_gpus()
+    n = max(1, min(n_gpus or n_vis, max(n_vis, 1), len(units)))
+    out = [None] * len(units)
+    if n <= 1:
+        for i, u in enumerate(units):
+            if prepare is not None:
+                u = prepare(u)
+            r = _run_one(fit_fn, u, shared, args, "cuda:0")
+            r["unit_index"], r["gpu"] = i, 0
+            out[i] = r
+            if "error" in r:
+                log(f"replicate {r['name']} FAILED: {r['error']}")
+        return out
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    tasks, results = ctx.Queue(maxsize=2 * n), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(g, fit_fn, shared, args, prepare, tasks, results), daemon=True)
+             for g in range(n)]
+    for p in procs:
+        p.start()
+    sent = got = 0
+    while got < len(units):
+        while sent < len(units) and not tasks.full():
+            tasks.put((sent, units[sent]))
+            sent += 1
+        r = results.get()
+        out[r["unit_index"]] = r
+        got += 1
+        if "error" in r:
+            log(f"replicate {r['name']} FAILED on GPU {r['gpu']}: {r['error']}")
+        else:
+            log(f"replicate {r['name']} done on GPU {r['gpu']} in {r.get('seconds', 0):.1f} s")
+    for _ in procs:
+        tasks.put(None)
+    for p in procs:
+        p.join()
+    return out
+
+
+def run_units_distributed(units, args, fit_fn, shared=None, prepare=None, device=None):
+    """One-process-per-GPU launches (torch.distributed.run): rank r fits units r, r+world, ...;
+    the small result records are exchanged with all_gather_object (control plane only)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = {}
+    for i in shard_static(len(units), rank, world):
+        u = units[i]
+        if prepare is not None:
+            u = prepare(u)
+        r = _run_one(fit_fn, u, shared, args, device or "cuda:0")
+        r["unit_index"], r["gpu"] = i, rank
+        mine[i] = r
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    out = [None] * len(units)
+    for part in gathered:
+        for i, r in part.items():
+            out[i] = r
+    return out

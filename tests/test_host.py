@@ -1,0 +1,241 @@
+"""Host logic that needs no GPU: ingest + filters against the reference's fixture, flag surface,
+RNG-order parity of the replicate plans, and replicate sharding (incl. 2 ranks over gloo)."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from locator_amd import genotypes as G
+from locator_amd import locator as L
+from locator_amd import replicates as R
+from oracle import locator_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+VCF = os.path.join(GOLD, "test_genotypes.vcf.gz")
+SAMPLES = os.path.join(GOLD, "test_sample_data.txt")
+
+
+@pytest.fixture(scope="module")
+def fixture_vcf():
+    return G.read_vcf(VCF)
+
+
+# ------------------------------------------------------------------ ingest
+def test_vcf_fixture_shape_and_filters(fixture_vcf):
+    """SURVEY.md §4 fixture characterisation: 11,527 records x 500 samples, allelism {1:5055, 2:6467, 3:5},
+    K = 5,830 after biallelic + allele-1 count >= 2, values {0: 78.0 %, 1: 11.2 %, 2: 10.9 %}."""
+    gt = fixture_vcf["calldata/GT"]
+    assert gt.shape == (11527, 500, 2) and gt.dtype == np.int8
+    assert list(fixture_vcf["samples"][:2]) == ["msp_0", "msp_1"] and fixture_vcf["samples"][-1] == "msp_499"
+    pos = fixture_vcf["variants/POS"]
+    assert pos[0] == 197 and pos[-1] == 2499926 and np.all(np.diff(pos) > 0)
+    assert gt.min() == 0 and gt.max() == 2
+    ac = G.count_alleles(gt)
+    assert np.bincount((ac > 0).sum(1)).tolist() == [0, 5055, 6467, 5]
+    a = G.filter_snps(gt, 2, verbose=False)
+    assert a.shape == (5830, 500) and a.dtype == np.int8
+    frac = np.bincount(a.ravel()) / a.size
+    assert np.allclose(frac, [0.7775, 0.1116, 0.1109], atol=1e-4)     # SURVEY: 78.0 / 11.2 / 10.9 % (rounded)
+    assert G.filter_snps(gt, 1, verbose=False).shape[0] == 6467          # min_mac == 1 skips the count filter
+
+
+def test_vcf_parser_general_calls(tmp_path):
+    p = tmp_path / "t.vcf"
+    p.write_text("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\ts3\n"
+                 "1\t10\t.\tA\tT\t.\tPASS\t.\tGT\t0|1\t./.\t1/1\n"
+                 "1\t20\t.\tA\tT,G\t.\tPASS\t.\tGT:DP\t0/2:5\t1|.:3\t10/1:9\n")
+    v = G.read_vcf(str(p))
+    assert v["calldata/GT"].tolist() == [[[0, 1], [-1, -1], [1, 1]], [[0, 2], [1, -1], [10, 1]]]
+    assert v["variants/POS"].tolist() == [10, 20] and list(v["samples"]) == ["s1", "s2", "s3"]
+    gt = v["calldata/GT"]
+    assert G.is_missing(gt).tolist() == [[False, True, False], [False, True, False]]
+    assert G.to_allele_counts_1(gt).tolist() == [[1, 0, 2], [0, 1, 1]]
+    assert G.count_alleles(gt, 2).tolist() == [[1, 3, 0], [1, 2, 1]]
+
+
+def test_impute_missing_consumes_rng_in_site_major_order():
+    rng = np.random.default_rng(0)
+    gt = rng.integers(0, 2, (6, 5, 2)).astype(np.int8)
+    gt[1, 3] = -1
+    gt[4, 0] = -1
+    gt[4, 2, 1] = -1
+    np.random.seed(7)
+    ac = G.replace_md(gt.copy())
+    dc = (gt == 1).reshape(6, -1).sum(1)
+    nind = (~(gt < 0).any(2)).sum(1)
+    np.random.seed(7)
+    exp = [(1, 3, np.random.binomial(2, dc[1] / (2 * nind[1]))), (4, 0, np.random.binomial(2, dc[4] / (2 * nind[4]))),
+           (4, 2, np.random.binomial(2, dc[4] / (2 * nind[4])))]
+    for i, j, v in exp:
+        assert ac[i, j] == v
+    untouched = ~(gt < 0).any(2)
+    assert np.array_equal(ac[untouched], (gt == 1).sum(2)[untouched])
+
+
+@pytest.mark.parametrize("compressor", [None, "zlib"])
+def test_zarr_v2_roundtrip_and_window_slices(tmp_path, compressor):
+    rng = np.random.default_rng(1)
+    gt = rng.integers(0, 2, (1000, 17, 2)).astype(np.int8)
+    pos = np.sort(rng.choice(10**6, 1000, replace=False)).astype(np.int32)
+    samples = np.array([f"s{i}" for i in range(17)])
+    store = str(tmp_path / "c.zarr")
+    G.write_callset_zarr(store, gt, pos, samples, chunk_variants=128, compressor=compressor)
+    cs = G.open_group(store, mode="r")
+    z = cs["calldata/GT"]
+    assert z.shape == (1000, 17, 2)
+    assert np.array_equal(z[:], gt) and np.array_equal(z[100:777, :, :], gt[100:777])
+    assert np.array_equal(z[127:129], gt[127:129]) and z[5:5].shape == (0, 17, 2)
+    assert np.array_equal(np.array(cs["variants/POS"]), pos)
+    assert list(np.asarray(cs["samples"][:]).astype(str)) == list(samples)
+
+
+def test_zarr_vlen_utf8_samples_and_unsupported_compressor(tmp_path):
+    import struct
+    d = tmp_path / "s"
+    d.mkdir()
+    names = ["AB0001", "x", "sample-3"]
+    raw = struct.pack("<I", 3) + b"".join(struct.pack("<I", len(n)) + n.encode() for n in names)
+    (d / "0").write_bytes(raw)
+    (d / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": [3], "chunks": [3], "dtype": "|O",
+                                           "compressor": None, "fill_value": 0, "order": "C",
+                                           "filters": [{"id": "vlen-utf8"}]}))
+    assert list(G.ZarrArray(str(d))[:]) == names
+    (d / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": [3], "chunks": [3], "dtype": "<i4",
+                                           "compressor": {"id": "blosc", "cname": "lz4"}, "fill_value": 0,
+                                           "order": "C", "filters": None}))
+    with pytest.raises(ValueError, match="blosc"):
+        G.ZarrArray(str(d))
+
+
+def test_matrix_reader_equals_count_semantics(tmp_path):
+    p = tmp_path / "m.txt"
+    p.write_text("sampleID\ta\tb\tc\nmsp1\t0\t1\t2\nmsp2\t2\t0\t1\n")
+    gt, samples = G.read_matrix(str(p))
+    assert list(samples) == ["msp1", "msp2"] and gt.shape == (3, 2, 2)
+    assert G.to_allele_counts_1(gt).T.tolist() == [[0, 1, 2], [2, 0, 1]]
+
+
+# ------------------------------------------------------------------ CLI surface
+REFERENCE_FLAGS = {   # name: default — /root/reference/locator/locator.py:13-166, in declaration order
+    "vcf": None, "zarr": None, "matrix": None, "sample_data": None, "train_split": 0.9, "windows": False,
+    "window_start": 0, "window_stop": None, "window_size": 5e5, "bootstrap": False, "jacknife": False,
+    "jacknife_prop": 0.05, "nboots": 50, "batch_size": 32, "max_epochs": 5000, "patience": 100, "min_mac": 2,
+    "max_SNPs": None, "impute_missing": False, "dropout_prop": 0.25, "nlayers": 10, "width": 256, "out": None,
+    "seed": None, "gpu_number": None, "plot_history": True, "keep_weights": False, "load_params": None,
+    "keras_verbose": 1}
+
+
+def test_flag_surface_matches_reference_and_params_json(tmp_path):
+    ns = vars(L.build_parser().parse_args([]))
+    keys = list(ns)
+    assert keys[:len(REFERENCE_FLAGS)] == list(REFERENCE_FLAGS)          # same names, same order
+    for k, v in REFERENCE_FLAGS.items():
+        assert ns[k] == v, k
+    # window flags stay untyped strings on the command line; plot_history is type=bool (Q5)
+    ns2 = L.build_parser().parse_args(["--window_size", "2000000", "--plot_history", "False"])
+    assert ns2.window_size == "2000000" and ns2.plot_history is True
+    out = str(tmp_path / "run")
+    a = L._setup(["--vcf", "x.vcf", "--sample_data", "s.txt", "--out", out, "--seed", "12345"])
+    js = json.load(open(out + "_params.json"))
+    assert list(js)[:len(REFERENCE_FLAGS)] == list(REFERENCE_FLAGS) and js["seed"] == 12345 and js["out"] == out
+    # --load_params replaces every argument, including out; a reference-written json loads too
+    ref_like = {k: js[k] for k in REFERENCE_FLAGS}
+    ref_like["out"] = str(tmp_path / "other")
+    json.dump(ref_like, open(str(tmp_path / "p.json"), "w"))
+    b = L._setup(["--out", out, "--load_params", str(tmp_path / "p.json")])
+    assert b.out == ref_like["out"] and b.gpus is None and os.path.exists(ref_like["out"] + "_params.json")
+
+
+def test_pipeline_rng_order_matches_reference_known_answers(fixture_vcf, tmp_path):
+    """sort_samples -> normalize_locs -> filter_snps -> split_train_test on the fixture with --seed 12345
+    reproduces SURVEY.md §4's known answers (validation indices, bootstrap reseed, site order)."""
+    L._setup(["--vcf", VCF, "--sample_data", SAMPLES, "--out", str(tmp_path / "o"), "--seed", "12345",
+              "--bootstrap", "--nboots", "2"])
+    gt, samples = fixture_vcf["calldata/GT"], fixture_vcf["samples"]
+    sd, locs = L.sort_samples(samples, gt)
+    assert np.isnan(locs[:50]).all() and not np.isnan(locs[50:]).any()
+    ml, sl, ma, sa, nlocs = L.normalize_locs(locs)
+    assert abs(sl - 14.3074) < 1e-3 and abs(sa - 14.0966) < 1e-3
+    oml, osl, oma, osa, olocs = O.normalize_locs(locs)
+    assert (ml, sl, ma, sa) == (oml, osl, oma, osa) and np.allclose(nlocs[50:], olocs[50:], rtol=0, atol=1e-15)
+    ac = L.filter_snps(gt)
+    train, test, tg, vg, tl, vl, pred, pg = L.split_train_test(ac, nlocs)
+    assert list(test[:10]) == [465, 459, 233, 149, 429, 423, 454, 140, 489, 165]
+    assert hashlib.sha1(test.astype("int64").tobytes()).hexdigest()[:16] == "144d3567059195b1"
+    assert (len(train), len(test), len(pred)) == (405, 45, 50) and tg.shape == (405, 5830)
+    units = L._bootstrap_units(tg.shape[1])
+    assert [u["boot"] for u in units] == ["FULL", 0, 1] and [u["replicate"] for u in units] == [0, 1, 2]
+    assert list(units[1]["site_order"][:8]) == [1092, 5266, 5679, 4778, 3551, 2418, 1321, 5729]
+    # the oracle's restatement of the same chain agrees
+    np.random.seed(12345)
+    O.split_train_test(ac, nlocs, 0.9)
+    chain = O.bootstrap_chain(2, 5830)
+    assert chain[0][0] == 812135 and np.array_equal(chain[1][1], units[2]["site_order"])
+
+
+# ------------------------------------------------------------------ replicate sharding
+def _fake_fit(unit, device="cpu"):
+    if unit.get("explode"):
+        raise RuntimeError("boom")
+    v = float(np.sum(unit["payload"]) + unit["shared_bias"]) * (unit["replicate"] + 1)
+    return {"name": unit["name"], "value": v, "seconds": 0.0, "args_out": unit["args"].out}
+
+
+class _Args:
+    out = "stem"
+
+
+def _units(n):
+    return [dict(name=f"u{i}", replicate=i, payload=np.arange(i + 3)) for i in range(n)]
+
+
+def test_run_units_sequential_order_and_failure_isolation():
+    units = _units(5)
+    units[2]["explode"] = True
+    logs = []
+    res = R.run_units(units, _Args(), _fake_fit, n_gpus=1, shared={"shared_bias": 10.0}, log=logs.append)
+    assert [r["unit_index"] for r in res] == [0, 1, 2, 3, 4]
+    assert "error" in res[2] and "boom" in res[2]["error"] and any("FAILED" in l for l in logs)
+    for i in (0, 1, 3, 4):
+        assert res[i]["value"] == (sum(range(i + 3)) + 10.0) * (i + 1) and res[i]["args_out"] == "stem"
+
+
+def test_shard_static_partitions_units():
+    for n, w in [(10, 4), (3, 8), (257, 8), (0, 2)]:
+        parts = [R.shard_static(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = R.run_units_distributed(_units(7), _Args(), _fake_fit, shared={"shared_bias": 1.0}, device="cpu")
+    q.put((rank, [(r["unit_index"], r["gpu"], r["value"]) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_units_distributed_gloo_world2_matches_single_process():
+    """N > 1 path on CPU: 2 ranks over gloo, round-robin units, results gathered on every rank and equal
+    to the 1-process run (per-unit results depend on the replicate index only, not on the rank)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single = R.run_units(_units(7), _Args(), _fake_fit, n_gpus=1, shared={"shared_bias": 1.0})
+    for rank in (0, 1):
+        assert [v for _, _, v in got[rank]] == [r["value"] for r in single]
+        assert [g for _, g, _ in got[rank]] == [i % 2 for i in range(7)]
