@@ -186,8 +186,15 @@ def main():
             lib.loc_event_destroy(h)
         t_mean = float(np.mean(ms)) * 1e-3
         achieved = float(np.mean(by)) / t_mean / 1e9
+        traffic = None
+        try:    # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm["workload"] == {"K": K, "H": H, "n": n}:
+                traffic = int(pm["kernels"]["l1_bwd_adam_kernel<%d>" % ((H + 31) // 32)]["traffic_bytes"])
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": "l1_bwd_adam_kernel", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(np.mean(by)), "us_per_launch": round(t_mean * 1e6, 2),
                 "launches_timed": len(ms)}
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-launch HBM traffic.
+
+Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+  FETCH_SIZE, WRITE_SIZE are in KiB (hbm_bytes = counter * 1024);
+  on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming
+  read -> doubled for kernels whose reads are such streams (flagged per kernel below);
+  WRITE_SIZE is uncalibrated by the guide -> calibrated here on a known byte count in the same run:
+  the ModelCheckpoint snapshot, a device-to-device copy of n_total floats (`__amd_rocclr_copyBuffer`).
+
+usage: pmc_traffic.py <fetch_dir>/f_counter_collection.csv <write_dir>/w_counter_collection.csv out.json
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer")
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[name].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, [0.0])
+        w = write.get(k, [0.0])
+        f_mean, w_mean = sum(f) / len(f), sum(w) / len(w)
+        wide = any(k.startswith(p) for p in WIDE_STREAM_READ)
+        rd = f_mean * 1024 * (2 if wide else 1)
+        out[k] = {"launches": len(f), "FETCH_SIZE_KiB_mean": f_mean, "WRITE_SIZE_KiB_mean": w_mean,
+                  "fetch_doubled_for_wide_stream": wide, "read_bytes": rd, "write_bytes": w_mean * 1024,
+                  "traffic_bytes": rd + w_mean * 1024, "FETCH_max": max(f), "WRITE_max": max(w)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        if v["traffic_bytes"] > 1e6:
+            print(f"{k[:44]:44s} n={v['launches']:5d} read={v['read_bytes']/1e6:9.2f} MB write={v['write_bytes']/1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
