@@ -1,0 +1,92 @@
+"""Committed "restated-oracle" vectors (tests/golden/make_golden.py).  CPU: the oracle and the host
+callback machines still reproduce them (regression pin).  GPU: the HIP path, through the C ABI,
+reproduces them from the stored inputs alone."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import locator_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["toy_16x64", "fixture_64x512"]
+
+
+def _params(z, prefix):
+    nl = int(z["nlayers"])
+    p = {"gamma": z[prefix + "gamma"], "beta": z[prefix + "beta"],
+         "W": [z[f"{prefix}W{i}"] for i in range(nl + 2)], "b": [z[f"{prefix}b{i}"] for i in range(nl + 2)]}
+    if prefix + "mov_mean" in z:
+        p["mov_mean"], p["mov_var"] = z[prefix + "mov_mean"], z[prefix + "mov_var"]
+    return p
+
+
+def _batches(z):
+    for b, m in zip(z["batches"], z["masks"]):
+        nb = int((b >= 0).sum())
+        yield b[:nb], m[:nb]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(name):
+    z = np.load(os.path.join(GOLD, f"oracle_{name}.npz"))
+    x, y, drop_p = z["x"], z["y"], float(z["drop_p"])
+    p = O.copy_params(_params(z, "p0_"))
+    b0, m0 = next(_batches(z))
+    loss, g, yhat = O.loss_and_grads(O.copy_params(p), x[b0], y[b0], m0, drop_p)
+    assert loss == float(z["loss0"]) and np.array_equal(yhat, z["yhat0"])
+    assert np.array_equal(g["W"][0], z["g0_W0"]) and np.array_equal(g["gamma"], z["g0_gamma"])
+    m, v = O.zeros_like_trainable(p), O.zeros_like_trainable(p)
+    losses = [O.train_step(p, m, v, t, 1e-3, x[b], y[b], mk, drop_p) for t, (b, mk) in enumerate(_batches(z), 1)]
+    assert np.allclose(losses, z["losses"], rtol=0, atol=1e-14)
+    ref = _params(z, "p5_")
+    for l in range(len(p["W"])):
+        assert np.allclose(p["W"][l], ref["W"][l], rtol=0, atol=1e-14)
+    assert np.allclose(p["mov_var"], ref["mov_var"], rtol=0, atol=1e-14)
+    assert np.allclose(O.predict(p, x), z["pred5"], rtol=0, atol=1e-13)
+
+
+def test_callback_traces_match_golden_for_oracle_and_host_machines():
+    from locator_amd.train import Callbacks
+    z = np.load(os.path.join(GOLD, "oracle_callbacks.npz"))
+    for cls in (O.Callbacks, Callbacks):
+        cb = cls(patience=12)
+        tr = [cb.on_epoch_end(e, float(v)) for e, v in enumerate(z["val_loss"])]
+        assert [t[0] for t in tr] == z["save"].tolist()
+        assert [t[1] for t in tr] == z["stop"].tolist()
+        assert [t[2] for t in tr] == z["lr"].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_path_reproduces_golden(name):
+    """fp32 HIP path vs stored float64 vectors: loss 2e-5, weights after 1 step 1e-5, after 5 steps 3e-5
+    (5 Adam updates of <= 1e-3 each), predictions 1e-3 relative."""
+    import torch
+    from tests.gpu_util import build_net, maxerr
+    z = np.load(os.path.join(GOLD, f"oracle_{name}.npz"))
+    x, y, drop_p = z["x"], z["y"], float(z["drop_p"])
+    net = build_net(x, y, _params(z, "p0_"), drop_p=drop_p)
+    Hp = net.d.Hp
+    loss = torch.zeros(5, device="cuda")
+    for t, (b, mk) in enumerate(_batches(z), 1):
+        rows = np.zeros(32, np.int32)
+        rows[:len(b)] = b
+        mask = np.zeros((32, Hp), np.uint8)
+        mask[:len(b), :mk.shape[1]] = mk
+        net.train_step(torch.from_numpy(rows).cuda(), len(b), t, torch.from_numpy(mask).cuda(), loss[t - 1:])
+        if t == 1:
+            torch.cuda.synchronize()
+            got, ref = net.export_params(), _params(z, "p1_")
+            assert max(maxerr(got["W"][l], ref["W"][l]) for l in range(len(ref["W"]))) < 1e-5
+            assert maxerr(got["gamma"], ref["gamma"]) < 1e-5 and maxerr(got["mov_mean"], ref["mov_mean"]) < 1e-6
+    torch.cuda.synchronize()
+    assert maxerr(loss.cpu().numpy(), z["losses"]) < 1e-4
+    got, ref = net.export_params(), _params(z, "p5_")
+    assert max(maxerr(got["W"][l], ref["W"][l]) for l in range(len(ref["W"]))) < 3e-5
+    n = x.shape[0]
+    yhat = torch.zeros((n, 2), device="cuda")
+    net.predict_rows(torch.arange(n, dtype=torch.int32, device="cuda"), n, yhat)
+    torch.cuda.synchronize()
+    rel = np.abs(yhat.cpu().numpy() - z["pred5"]) / np.maximum(np.abs(z["pred5"]), 1.0)
+    assert rel.max() < 1e-3
