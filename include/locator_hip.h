@@ -86,6 +86,8 @@ typedef struct loc_net {
     int64_t x_pitch;
     const float* Y;          /* [n_samples][2] z-scored targets (locator.py:284-292)  */
     float drop_p;            /* --dropout_prop                                        */
+    float* wht;              /* (L-1)*Hp*Hp: transposed hidden kernels (derived state, kept in sync by
+                                loc_stack_dw_adam; refresh with loc_transpose_hidden after loading weights) */
     /* workspace, sized by loc_workspace_floats() */
     float* ws;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
@@ -165,6 +167,30 @@ int loc_head_train(const float* a, int Hp, int n_b, const int32_t* rows, const f
 /* Inference: yhat[b][0..1]; if rows/Y non-NULL also dist[b] = ||yhat - Y[rows[b]]||. */
 int loc_head_eval(const float* a, int Hp, int n_b, const float* wa, const float* ba, const float* wb,
                   const float* bb, float* yhat, const int32_t* rows, const float* Y, float* dist, void* stream);
+
+/* ---- fused hidden stack (widths that pad to 64/128/256/512; otherwise the per-layer entry points above) ---- */
+int loc_stack_fused_supported(int Hp);
+/* WhT[l] = Wh[l]^T for the n_hidden = L-1 hidden kernels. */
+int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_hidden, void* stream);
+/* ONE launch: layers 2..L forward (+Dropout), Dense(2) x2, per-sample loss, and the whole backward chain down
+ * to dz of layer 1.  Row-parallel (2 batch rows per workgroup), no inter-workgroup traffic.  Outputs: acts
+ * [L][32][Hp] (ELU outputs; slot 0 = layer 1 is an input), adrop, dz [L][32][Hp], head_out [32][8]. */
+int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
+                               const float* wa, const float* ba, const float* wb, const float* bb,
+                               const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
+                               const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
+                               float* head_out, void* stream);
+/* Inference counterpart: layers 2..L + heads for n_b <= 32 rows; yhat[n_b][2], optional dist[n_b]. */
+int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
+                           const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
+                           const float* Y, float* yhat, float* dist, void* stream);
+/* ONE launch: dW, db + Adam for every hidden layer (one workgroup per 32x32 tile, W^T refreshed), head
+ * gradients + Adam, and the batch-mean loss (to *loss_out). */
+int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts, const float* adrop,
+                      const float* dz, const float* head_out, float* params, float* adam_m, float* adam_v,
+                      float* WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba, int64_t off_wb,
+                      int64_t off_bb, float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
+                      const int* t_base, int t_off, void* stream);
 
 /* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).

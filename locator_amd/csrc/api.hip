@@ -56,7 +56,7 @@ extern "C" int loc_param_layout(const loc_dims* d, loc_layout* o) {
 extern "C" int64_t loc_w1s_index(int h, int k, int Hp) { return w1s_index(h, k, Hp / 32); }
 
 struct ws_view {
-    float *bn4, *gbs, *partial, *acts, *adrop, *dz;
+    float *bn4, *gbs, *partial, *acts, *adrop, *dz, *head_out;
 };
 static ws_view carve(const loc_dims* d, float* ws) {
     ws_view v;
@@ -67,11 +67,12 @@ static ws_view carve(const loc_dims* d, float* ws) {
     v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk;
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
+    v.head_out = v.dz + d->L * blk;
     return v;
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
     const int64_t blk = 32 * (int64_t)d->Hp;
-    return 8 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk;
+    return 8 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk + 256;
 }
 
 #define TRY(x)                 \
@@ -105,6 +106,22 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         const bool dr = use_drop && npre == 1;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                            net->l1_fwd_grid, act(1), dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
+    }
+    if (net->wht && loc_stack_fused_supported(Hp)) {
+        // fused row-parallel hidden stack: 2 launches instead of 2(L-1)+2
+        TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
+                                       P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, rows,
+                                       net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
+        TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+                              net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl, net->lr,
+                              net->t_base, t_off, stream));
+        if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
+        TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
+                                 V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,
+                                 V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
+                                 net->t_base, t_off, net->l1_bwd_grid, stream));
+        if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+        return 0;
     }
     for (int l = 2; l <= L; ++l) {
         const bool dr = use_drop && l == npre;
@@ -155,6 +172,13 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         const int nb = n - i < LOC_ROWS ? n - i : LOC_ROWS;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows + i, nb, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                            net->l1_fwd_grid, w.acts, nullptr, nullptr, 1.f, stream));
+        if (loc_stack_fused_supported(Hp)) {
+            TRY(loc_stack_forward_eval(w.acts, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
+                                       P + lay.bb, Hp, L, nb, with_targets ? rows + i : nullptr,
+                                       with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)i,
+                                       with_targets ? dist + i : nullptr, stream));
+            continue;
+        }
         for (int l = 2; l <= L; ++l)
             TRY(loc_dense_forward(w.acts + (l - 2) * blk, P + lay.wh + (l - 2) * HH,
                                   P + lay.bh + (int64_t)(l - 2) * Hp, Hp, w.acts + (l - 1) * blk, nullptr, nullptr,

@@ -1,0 +1,456 @@
+// Row-parallel fused hidden stack (reference: /root/reference/locator/locator.py:319-325, :314-315).
+//
+// The rows of a minibatch are independent through every Dense+ELU layer, the Dropout, the two
+// Dense(2) heads and the per-sample Euclidean loss; only the weight gradients reduce over rows.  So
+// instead of one launch per layer (latency-bound: ~5 us each, 20 per step), ONE launch carries each
+// group of R batch rows through all layers forward, the heads and the loss, and all layers
+// backward, with no communication between workgroups at all.  Every workgroup streams each layer's
+// 256 KB kernel from L2 (coalesced 16-byte loads; the backward pass reads a transposed copy kept in
+// sync by the Adam kernel), contracting on the vector ALU (R rows is far below an MFMA tile).  The
+// row-reducing work — dW, db and Adam for all hidden layers and the heads, and the batch loss — runs
+// afterwards in ONE wide launch (stack_dw_all_kernel), one workgroup per 32x32 weight tile.
+#include "common.h"
+
+#define SF_THREADS 512
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for
+// the weight prefetch that is deliberately kept in flight across the reduction phases.  Inside
+// stack_fused_kernel no thread ever reads another thread's GLOBAL writes, so LDS ordering is all the
+// barrier has to provide ("memory" keeps the compiler from moving accesses across it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NHT, int R, bool TRAIN>
+__global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
+    const float* __restrict__ a1_in, const float* __restrict__ Wh, const float* __restrict__ WhT,
+    const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba,
+    const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
+    int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
+    float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
+    float* __restrict__ yhat, float* __restrict__ dist) {
+    constexpr int Hp = NHT * 32;
+    constexpr int C4 = Hp / 4;               // float4 columns per weight row
+    constexpr int KG = SF_THREADS / C4;      // k-groups
+    constexpr int KPG = Hp / KG;             // k per group
+    static_assert(SF_THREADS % C4 == 0 && Hp % KG == 0 && KPG >= 1, "unsupported width for the fused stack");
+    __shared__ __attribute__((aligned(16))) float act[R][Hp];          // current layer input (rows of this block)
+    __shared__ __attribute__((aligned(16))) float part[KG][R][Hp];     // per-k-group partial sums
+    __shared__ float hs[R][8];
+
+    const int t = threadIdx.x, c4 = t % C4, kq = t / C4;
+    const int r0 = blockIdx.x * R;
+    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+
+    // rows of this block: input of layer 2
+    for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = a1_in[(int64_t)(r0 + i / Hp) * Hp + i % Hp];
+    __syncthreads();
+
+    // out[r][n] = sum_k in[r][k] * Wcur[k][n]: partial over this thread's k-group, reduced over groups later.
+    // The weight stream is software-pipelined: two register buffers of CH rows; while one is consumed
+    // the other is in flight, and the first chunk of the NEXT layer's kernel is requested before this
+    // layer's reduction so L2 latency never sits on the chain.  Chunk 0 of Wcur is already in bufA.
+    constexpr int CH = (KPG / 2) < 16 ? (KPG / 2) : 16;
+    constexpr int NCH = KPG / CH;
+    static_assert(KPG >= 2 && NCH % 2 == 0, "k-group must split into an even number of chunks");
+    f32x4 bufA[CH], bufB[CH];
+    auto load_chunk = [&](const float* __restrict__ Wsrc, int c, f32x4 (&buf)[CH]) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(Wsrc) + (int64_t)(kq * KPG + c * CH) * C4 + c4;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) buf[j] = wp[(int64_t)j * C4];
+    };
+    auto fma_chunk = [&](int c, const f32x4 (&buf)[CH], f32x4 (&acc)[R]) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float a = act[r][kq * KPG + c * CH + j];
+                acc[r][0] = fmaf(a, buf[j][0], acc[r][0]);
+                acc[r][1] = fmaf(a, buf[j][1], acc[r][1]);
+                acc[r][2] = fmaf(a, buf[j][2], acc[r][2]);
+                acc[r][3] = fmaf(a, buf[j][3], acc[r][3]);
+            }
+        }
+    };
+    // On entry chunks 0 and 1 of Wcur are in bufA / bufB (or in flight).  Each buffer is refilled with the
+    // chunk two ahead the moment it has been consumed; past the end of this layer that is the NEXT pass's
+    // kernel (Wnext is always a valid matrix: the last pass prefetches a dummy), so ~a whole layer
+    // (256 KB per workgroup) is in flight across the reduction phase and no load is conditional.
+    auto contract = [&](const float* __restrict__ Wcur, const float* __restrict__ Wnext) {
+        f32x4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < NCH; c += 2) {
+            const bool wrap = c + 2 >= NCH;
+            const float* Wn = wrap ? Wnext : Wcur;
+            const int cn = wrap ? c + 2 - NCH : c + 2;
+            fma_chunk(c, bufA, acc);
+            load_chunk(Wn, cn, bufA);
+            fma_chunk(c + 1, bufB, acc);
+            load_chunk(Wn, cn + 1, bufB);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(&part[kq][r][4 * c4]) = acc[r];
+    };
+    // weight matrix of pass p: forward layers 2..L use Wh[0..L-2]; backward L..2 use WhT[L-2..0]
+    const int n_pass = TRAIN ? 2 * (L - 1) : (L - 1);
+    auto wseq = [&](int p) -> const float* {
+        if (p >= n_pass) return Wh;                      // dummy prefetch after the last pass
+        return p < L - 1 ? Wh + (int64_t)p * HH : WhT + (int64_t)(2 * (L - 1) - 1 - p) * HH;
+    };
+    load_chunk(wseq(0), 0, bufA);
+    load_chunk(wseq(0), 1, bufB);
+    auto reduced = [&](int r, int n) {     // fixed-order sum over the k-groups
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) s += part[g][r][n];
+        return s;
+    };
+
+    // per-thread output slots of the epilogues: element i = t + SF_THREADS*o of the R x Hp block
+    constexpr int NO = (R * Hp + SF_THREADS - 1) / SF_THREADS;
+    // head operands requested now; consumed after the forward chain
+    float h_wa0 = 0.f, h_wa1 = 0.f;
+    if (t < Hp) { h_wa0 = wa[2 * t]; h_wa1 = wa[2 * t + 1]; }
+    float h_ba0 = 0.f, h_ba1 = 0.f, h_w00 = 0.f, h_w01 = 0.f, h_w10 = 0.f, h_w11 = 0.f, h_bb0 = 0.f, h_bb1 = 0.f;
+    float h_y0 = 0.f, h_y1 = 0.f;
+    if (t < R) {
+        h_ba0 = ba[0]; h_ba1 = ba[1]; h_w00 = wb[0]; h_w01 = wb[1]; h_w10 = wb[2]; h_w11 = wb[3];
+        h_bb0 = bb[0]; h_bb1 = bb[1];
+        if (Y != nullptr && r0 + t < n_b) { h_y0 = Y[(int64_t)rows[r0 + t] * 2]; h_y1 = Y[(int64_t)rows[r0 + t] * 2 + 1]; }
+    }
+
+    // ---------------- forward: layers 2..L
+    for (int l = 2; l <= L; ++l) {
+        const float* bias = bh + (int64_t)(l - 2) * Hp;
+        const bool dr = TRAIN && mask != nullptr && l == n_pre;
+        float e_bias[NO], e_keep[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {          // epilogue operands requested before the contraction
+            const int i = t + SF_THREADS * o;
+            e_bias[o] = 0.f; e_keep[o] = 1.f;
+            if (i < R * Hp) {
+                e_bias[o] = bias[i % Hp];
+                if (dr) e_keep[o] = mask[(int64_t)(r0 + i / Hp) * Hp + i % Hp] ? keep_scale : 0.f;
+            }
+        }
+        contract(wseq(l - 2), wseq(l - 1));
+        lds_barrier();
+        float* aout = acts + (int64_t)(l - 1) * blk;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int i = t + SF_THREADS * o;
+            if (i < R * Hp) {
+                const int r = i / Hp, n = i % Hp;
+                const float a = elu_f(reduced(r, n) + e_bias[o]);
+                const int64_t gi = (int64_t)(r0 + r) * Hp + n;
+                if (TRAIN) aout[gi] = a;
+                float nx = a;
+                if (dr) {
+                    nx = a * e_keep[o];
+                    adrop[gi] = nx;
+                }
+                act[r][n] = nx;
+            }
+        }
+        lds_barrier();
+    }
+
+    // ---------------- heads + loss (per row)
+    {
+        float p0[R], p1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+        if (t < Hp) {                   // Hp <= SF_THREADS: one k per thread
+#pragma unroll
+            for (int r = 0; r < R; ++r) { p0[r] = act[r][t] * h_wa0; p1[r] = act[r][t] * h_wa1; }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { p0[r] += __shfl_xor(p0[r], o); p1[r] += __shfl_xor(p1[r], o); }
+            if ((t & 63) == 0) { part[0][r][2 * (t >> 6)] = p0[r]; part[0][r][2 * (t >> 6) + 1] = p1[r]; }
+        }
+        lds_barrier();
+        if (t < R) {
+            const int r = t, b = r0 + r;
+            float y10 = h_ba0, y11 = h_ba1;
+            for (int w = 0; w < SF_THREADS / 64; ++w) { y10 += part[0][r][2 * w]; y11 += part[0][r][2 * w + 1]; }
+            const float w00 = h_w00, w01 = h_w01, w10 = h_w10, w11 = h_w11;
+            const float y20 = y10 * w00 + y11 * w10 + h_bb0;
+            const float y21 = y10 * w01 + y11 * w11 + h_bb1;
+            float d = 0.f, g0 = 0.f, g1 = 0.f;
+            const bool valid = b < n_b;
+            if (valid && Y != nullptr) {
+                const float e0 = y20 - h_y0, e1 = y21 - h_y1;
+                d = sqrtf(fmaxf(e0 * e0 + e1 * e1, 0.f));
+                if (d > 0.f) { g0 = e0 / d / (float)n_b; g1 = e1 / d / (float)n_b; }
+            }
+            if (TRAIN) {
+                const float dy10 = g0 * w00 + g1 * w01, dy11 = g0 * w10 + g1 * w11;
+                hs[r][0] = dy10; hs[r][1] = dy11;
+                float* ho = head_out + 8 * b;       // [d, dy1_0, dy1_1, y1_0, y1_1, dy2_0, dy2_1, -]
+                ho[0] = d; ho[1] = dy10; ho[2] = dy11; ho[3] = y10; ho[4] = y11; ho[5] = g0; ho[6] = g1; ho[7] = 0.f;
+            } else if (valid) {
+                yhat[2 * b] = y20; yhat[2 * b + 1] = y21;
+                if (dist) dist[b] = d;
+            }
+        }
+        lds_barrier();
+    }
+    if (!TRAIN) return;
+
+    // ---------------- dz_L = (dy1 . Wa^T) * ELU'(a_L), then backward through layers L..2
+    {
+        float* dzo = dz + (int64_t)(L - 1) * blk;
+        for (int i = t; i < R * Hp; i += SF_THREADS) {
+            const int r = i / Hp, k = i % Hp;
+            const float v = (hs[r][0] * wa[2 * k] + hs[r][1] * wa[2 * k + 1]) * elu_grad_from_act(act[r][k]);   // wa: L1/L2 hit
+            dzo[(int64_t)(r0 + r) * Hp + k] = v;
+            part[0][r][k] = v;     // staged; copied into act after the barrier (act is still being read)
+        }
+        lds_barrier();
+        for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = part[0][i / Hp][i % Hp];
+        lds_barrier();
+    }
+    for (int l = L; l >= 2; --l) {
+        const int p = (L - 1) + (L - l);             // pass index of this backward layer
+        const float* aprev = acts + (int64_t)(l - 2) * blk;      // ELU output of layer l-1 (pre-dropout)
+        const bool dr = mask != nullptr && l - 1 == n_pre;
+        float e_g[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {          // epilogue operands requested before the contraction
+            const int i = t + SF_THREADS * o;
+            e_g[o] = 0.f;
+            if (i < R * Hp) {
+                const int64_t gi = (int64_t)(r0 + i / Hp) * Hp + i % Hp;
+                float keep = 1.f;
+                if (dr) keep = mask[gi] ? keep_scale : 0.f;
+                e_g[o] = keep * elu_grad_from_act(aprev[gi]);
+            }
+        }
+        contract(wseq(p), wseq(p + 1));              // sum_n dz_l[r][n] * W_l[k][n] = dz_l . (W_l^T)[n][k]
+        lds_barrier();
+        float* dzo = dz + (int64_t)(l - 2) * blk;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int i = t + SF_THREADS * o;
+            if (i < R * Hp) {
+                const int r = i / Hp, k = i % Hp;
+                const float v = reduced(r, k) * e_g[o];
+                dzo[(int64_t)(r0 + r) * Hp + k] = v;
+                act[r][k] = v;
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Everything that reduces over the batch rows, for all hidden layers at once.
+// Blocks [0, (L-1)*NHT^2): one 32x32 tile of W_l (l = 2..L): dW = in_l^T dz_l on the matrix core (wave 0),
+//   Adam by all 512 threads, and the transposed copy W_l^T refreshed through LDS.  Tile row 0 also does db.
+// Last block: heads (dWa, dba, dWb, dbb + Adam) and the batch loss.
+// ---------------------------------------------------------------------------------------------
+template <int NHT>
+__global__ __launch_bounds__(512) void stack_dw_all_kernel(
+    int L, int n_pre, int n_b, int use_drop, const float* __restrict__ acts, const float* __restrict__ adrop,
+    const float* __restrict__ dz, const float* __restrict__ head_out, float* __restrict__ P, float* __restrict__ M,
+    float* __restrict__ V, float* __restrict__ WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
+    int64_t off_wb, int64_t off_bb, float* __restrict__ loss_out, const float* __restrict__ alpha_tab,
+    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off) {
+    constexpr int Hp = NHT * 32;
+    __shared__ float gt[32][33];
+    __shared__ float hsm[32][8];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
+    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
+    const int n_tiles = (L - 1) * NHT * NHT;
+
+    if ((int)blockIdx.x < n_tiles) {
+        const int li = blockIdx.x / (NHT * NHT);          // 0-based hidden index: layer l = li + 2
+        const int tile = blockIdx.x % (NHT * NHT);
+        const int kt = tile / NHT, nt = tile % NHT;
+        const int l = li + 2;
+        const float* in2 = (use_drop && l - 1 == n_pre) ? adrop : acts + (int64_t)(l - 2) * blk;
+        const float* dz2 = dz + (int64_t)(l - 1) * blk;
+        float* W2 = P + off_wh + li * HH;
+        float* mW2 = M + off_wh + li * HH;
+        float* vW2 = V + off_wh + li * HH;
+        float* WT2 = WhT + li * HH;
+        int64_t idx[2];
+        float wv[2], mv[2], vv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = t + 512 * i;
+            idx[i] = (int64_t)(kt * 32 + (e >> 5)) * Hp + nt * 32 + (e & 31);
+            wv[i] = W2[idx[i]]; mv[i] = mW2[idx[i]]; vv[i] = vW2[idx[i]];
+        }
+        if (w == 0) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int b = 2 * s + hi;
+                av[s] = in2[b * Hp + kt * 32 + jl];
+                bv[s] = dz2[b * Hp + nt * 32 + jl];
+            }
+            f32x16 g = {0};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gt[rowmap(r, hi)][jl] = g[r];
+            if (kt == 0) {
+                float sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sb += bv[i];
+                sb += __shfl_xor(sb, 32);
+                if (hi == 0) {
+                    const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + jl;
+                    float bw = P[o], bm = M[o], bvv = V[o];
+                    adam_update(bw, bm, bvv, sb, alpha);
+                    P[o] = bw; M[o] = bm; V[o] = bvv;
+                }
+            }
+        }
+        __syncthreads();
+        float nw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = t + 512 * i;
+            adam_update(wv[i], mv[i], vv[i], gt[e >> 5][e & 31], alpha);
+            W2[idx[i]] = wv[i]; mW2[idx[i]] = mv[i]; vW2[idx[i]] = vv[i];
+            nw[i] = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int e = t + 512 * i; gt[e >> 5][e & 31] = nw[i]; }   // [k][n]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {      // W^T[n][k], coalesced along k
+            const int e = t + 512 * i, n = e >> 5, k = e & 31;
+            WT2[(int64_t)(nt * 32 + n) * Hp + kt * 32 + k] = gt[k][n];
+        }
+        return;
+    }
+    // ---- head block
+    if (t < 256) hsm[t >> 3][t & 7] = head_out[t];
+    __syncthreads();
+    const float* aL = acts + (int64_t)(L - 1) * blk;
+    if (t == 0) {
+        float s = 0.f;
+        for (int b = 0; b < n_b; ++b) s += hsm[b][0];
+        loss_out[0] = s / (float)n_b;
+    }
+    if (t >= 64 && t < 72) {
+        const int q = t - 64;
+        float g = 0.f;
+        int64_t off;
+        if (q < 4) {            // dWb[i][j] = sum_b y1[b][i] dy2[b][j]
+            const int i = q >> 1, j = q & 1;
+            for (int b = 0; b < 32; ++b) g += hsm[b][3 + i] * hsm[b][5 + j];
+            off = off_wb + q;
+        } else if (q < 6) {     // dbb[j] = sum_b dy2[b][j]
+            for (int b = 0; b < 32; ++b) g += hsm[b][5 + (q - 4)];
+            off = off_bb + (q - 4);
+        } else {                // dba[c] = sum_b dy1[b][c]
+            for (int b = 0; b < 32; ++b) g += hsm[b][1 + (q - 6)];
+            off = off_ba + (q - 6);
+        }
+        float wv = P[off], mv = M[off], vv = V[off];
+        adam_update(wv, mv, vv, g, alpha);
+        P[off] = wv; M[off] = mv; V[off] = vv;
+    }
+    for (int k = t; k < Hp; k += 512) {      // dWa[k][c] = sum_b a_L[b][k] dy1[b][c]
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const float av = aL[b * Hp + k];
+            g0 = fmaf(av, hsm[b][1], g0);
+            g1 = fmaf(av, hsm[b][2], g1);
+        }
+        const int64_t o = off_wa + 2 * k;
+        float w0 = P[o], m0 = M[o], v0 = V[o], w1 = P[o + 1], m1 = M[o + 1], v1 = V[o + 1];
+        adam_update(w0, m0, v0, g0, alpha);
+        adam_update(w1, m1, v1, g1, alpha);
+        P[o] = w0; M[o] = m0; V[o] = v0; P[o + 1] = w1; M[o + 1] = m1; V[o + 1] = v1;
+    }
+}
+
+// hidden kernels -> transposed copies (after init / import / best-weight reload)
+__global__ void transpose_hidden_kernel(const float* __restrict__ Wh, float* __restrict__ WhT, int Hp, int nl) {
+    __shared__ float tile[32][33];
+    const int l = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = Wh + (int64_t)l * Hp * Hp;
+    float* dst = WhT + (int64_t)l * Hp * Hp;
+    for (int j = ty; j < 32; j += 8) tile[j][tx] = src[(int64_t)(by + j) * Hp + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) dst[(int64_t)(bx + j) * Hp + by + tx] = tile[tx][j];
+    (void)nl;
+}
+
+extern "C" int loc_stack_fused_supported(int Hp) { return Hp == 64 || Hp == 128 || Hp == 256 || Hp == 512; }
+
+#define SF_SWITCH(MACRO)                                                    \
+    switch (Hp) {                                                           \
+        case 64: MACRO(2); break;                                           \
+        case 128: MACRO(4); break;                                          \
+        case 256: MACRO(8); break;                                          \
+        case 512: MACRO(16); break;                                         \
+        default: loc_set_error("%s: fused stack needs width 64/128/256/512 after padding (got %d)", __func__, Hp); return -1; \
+    }
+
+extern "C" int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_hidden, void* stream) {
+    if (n_hidden <= 0) return 0;
+    hipLaunchKernelGGL(transpose_hidden_kernel, dim3(Hp / 32, Hp / 32, n_hidden), dim3(256), 0, (hipStream_t)stream, Wh,
+                       WhT, Hp, n_hidden);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+constexpr int SF_R = 2;   // batch rows per workgroup -> 16 workgroups per 32-row block
+
+extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
+                                          const float* wa, const float* ba, const float* wb, const float* bb,
+                                          const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
+                                          const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
+                                          float* head_out, void* stream) {
+#define LAUNCH(N)                                                                                                  \
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3(32 / SF_R), dim3(SF_THREADS), 0,                  \
+                       (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,  \
+                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr);
+    SF_SWITCH(LAUNCH)
+#undef LAUNCH
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa,
+                                      const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
+                                      const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+    const int nblk = (n_b + SF_R - 1) / SF_R;
+#define LAUNCH(N)                                                                                                 \
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3(nblk), dim3(SF_THREADS), 0, (hipStream_t)stream, \
+                       a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb, (const uint8_t*)nullptr, 1.f, L, 0, n_b, \
+                       rows, Y, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, yhat, dist);
+    SF_SWITCH(LAUNCH)
+#undef LAUNCH
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts,
+                                 const float* adrop, const float* dz, const float* head_out, float* params,
+                                 float* adam_m, float* adam_v, float* WhT, int64_t off_wh, int64_t off_bh,
+                                 int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb, float* loss_out,
+                                 const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
+                                 int t_off, void* stream) {
+    const int nht = Hp / 32;
+    const int grid = (L - 1) * nht * nht + 1;
+#define LAUNCH(N)                                                                                                 \
+    hipLaunchKernelGGL(stack_dw_all_kernel<N>, dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b,      \
+                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
+                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off);
+    SF_SWITCH(LAUNCH)
+#undef LAUNCH
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

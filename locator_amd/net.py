@@ -71,6 +71,10 @@ class LocatorNet:
         self.lr_t = torch.full((1,), 1e-3, dtype=torch.float32, device=dev)
         self.t_base_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ws = torch.empty(self.lib.loc_workspace_floats(C.byref(self.d)), dtype=torch.float32, device=dev)
+        # transposed hidden kernels for the fused backward chain (derived state, see refresh_transposed)
+        self.use_fused = bool(self.lib.loc_stack_fused_supported(self.d.Hp))
+        self.wht = (torch.zeros((self.d.L - 1) * self.d.Hp * self.d.Hp, dtype=torch.float32, device=dev)
+                    if self.use_fused else None)
         nkt = self.d.Kp // 32
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
@@ -87,6 +91,7 @@ class LocatorNet:
         n.lr, n.t_base = self.lr_t.data_ptr(), self.t_base_t.data_ptr()
         n.X, n.x_pitch, n.Y = self.X.data_ptr(), self.X.stride(0), self.Y.data_ptr()
         n.drop_p = self.drop_p
+        n.wht = self.wht.data_ptr() if self.wht is not None else None
         n.ws = self.ws.data_ptr()
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         self._net = n
@@ -118,6 +123,13 @@ class LocatorNet:
         _lib.check(lib.loc_init_glorot(p + 4 * lay.wb, 2, 2, 2, 2, 0, self.seed, sid(d.L + 1), st), "init Wb")
         self.t_base_t.zero_()
         self.lr_t.fill_(1e-3)
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        """WhT[l] = Wh[l]^T; needed whenever the hidden kernels are written by anything but the Adam kernel."""
+        if self.wht is not None:
+            _lib.check(self.lib.loc_transpose_hidden(self.params.data_ptr() + 4 * self.lay.wh, self.wht.data_ptr(),
+                                                     self.d.Hp, self.d.L - 1, _stream()), "loc_transpose_hidden")
 
     def _export_flat(self, flat, with_moving=True):
         """Flat device buffer -> dict in the oracle's format (Keras orientation, un-padded)."""
@@ -175,6 +187,7 @@ class LocatorNet:
 
     def import_params(self, p):
         self._import_flat(self.params, p)
+        self.refresh_transposed()
 
     # ------------------------------------------------------------------ ops
     def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None):
@@ -205,6 +218,7 @@ class LocatorNet:
         """model.load_weights(best) (locator.py:379-388)."""
         if self.best is not None:
             self.params.copy_(self.best)
+            self.refresh_transposed()
 
 
 def gather_columns(X, site_order, K):

@@ -48,7 +48,7 @@ def case(name, x, y, width, nlayers, drop_p, seed):
     for t, (b, mk) in enumerate(zip(batches, masks), start=1):
         losses.append(O.train_step(p, m, v, t, 1e-3, x[b], y[b], mk, drop_p))
         if t == 1:
-            out.update(flat(p, "p1_"))
+            out.update(flat(O.copy_params(p), "p1_"))     # copy: Adam updates p in place
     out["losses"] = np.array(losses)
     out.update(flat(p, "p5_"))
     out["pred5"] = O.predict(p, x)
