@@ -90,6 +90,11 @@ typedef struct loc_net {
                                 loc_stack_dw_adam; refresh with loc_transpose_hidden after loading weights) */
     /* workspace, sized by loc_workspace_floats() */
     float* ws;
+    /* optional overlap of the hidden-layer dW/Adam launch with the layer-1 backward: a second stream and two
+     * events (hipStream_t / hipEvent_t as void*), all NULL to stay on one stream */
+    void* side_stream;
+    void* ev_fork;
+    void* ev_join;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
 } loc_net;
@@ -127,6 +132,14 @@ int loc_w1_unswizzle(const float* w1s, int Kp, int Hp, float* w_kh, int K, int H
 int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, int K, int Kp,
                        const float* gamma, const float* beta, float* mov_mean, float* mov_var,
                        float* out4, void* stream);
+/* Whole epoch at once (the statistics depend only on X and the permutation): rows_all holds the epoch's
+ * n_steps minibatches back to back (`batch` rows each, the last one n_last rows).  Writes
+ * stats_ep[step] = [mean | biased var] (n_steps*2*Kp floats), applies the n_steps moving-statistics
+ * updates in order, and leaves bn4 = [scale|shift|mean|rstd] of step 0.  Later steps get their bn4 from
+ * loc_l1_backward_adam(bn_next_stats = stats_ep + 2*Kp*(step+1)) right after gamma/beta are updated. */
+int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last, int n_steps,
+                       int K, int Kp, const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                       float* stats_ep, float* bn4, void* stream);
 /* Inference: scale/shift from the moving statistics. */
 int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const float* beta, const float* mov_mean,
                              const float* mov_var, float* out4, void* stream);
@@ -139,12 +152,15 @@ int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n
                    float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
- * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel). */
+ * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats
+ * ([mean|var] of the NEXT minibatch, from loc_bn_epoch_stats) is non-NULL that kernel also writes the next
+ * step's [scale|shift|mean|rstd] to bn4_out from the just-updated gamma/beta. */
 int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                          const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
                          float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
                          float* b1, float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab,
-                         int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid, void* stream);
+                         int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid,
+                         const float* bn_next_stats, float* bn4_out, void* stream);
 
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,
@@ -195,15 +211,22 @@ int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const flo
 /* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).
  * mask: n_b*Hp keep flags for this step (NULL iff drop_p == 0).  loss_out: 1 float.
+ * bn_ready != 0: this step's [scale|shift|mean|rstd] is already in the workspace (loc_bn_epoch_stats or the
+ * previous step's bn_next_stats) and the per-step statistics kernel is skipped.
+ * bn_next_stats: [mean|var] of the next minibatch or NULL (see loc_l1_backward_adam).
  * ev_l1b0 / ev_l1b1: optional hipEvent_t recorded around the layer-1 backward kernel. */
 int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                   float* loss_out, void* ev_l1b0, void* ev_l1b1, void* stream);
+                   float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0, void* ev_l1b1,
+                   void* stream);
+/* The workspace's bn4 block (where loc_bn_epoch_stats must leave step 0's values). */
+float* loc_workspace_bn4(const loc_net* net);
 /* Inference forward over n rows (any n >= 0) in blocks of 32: yhat[n][2]; dist[n] if with_targets. */
 int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets, float* dist,
                 void* stream);
 
 /* thin event helpers so a ctypes host can time a kernel on the stream it runs on */
 int loc_event_create(void** ev);
+int loc_event_create_notiming(void** ev);
 int loc_event_destroy(void* ev);
 int loc_event_record(void* ev, void* stream);
 int loc_event_elapsed_ms(void* ev0, void* ev1, float* ms);

@@ -33,7 +33,7 @@ class Layout(C.Structure):
 class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
-                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
+                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -55,7 +55,12 @@ SIGNATURES = {
     "loc_l1_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                  C.c_float, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
-                                       vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+                                       vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
+                                       vp]),
+    "loc_bn_epoch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+                                     vp, vp, vp]),
+    "loc_workspace_bn4": (vp, [C.POINTER(Net)]),
+    "loc_event_create_notiming": (C.c_int, [C.POINTER(vp)]),
     "loc_dense_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, vp]),
     "loc_dense_backward": (C.c_int, [vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                      C.c_int, vp, vp, C.c_int, vp]),
@@ -70,7 +75,7 @@ SIGNATURES = {
     "loc_stack_dw_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                     C.c_int, vp, vp, C.c_int, vp]),
-    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),
     "loc_event_destroy": (C.c_int, [vp]),

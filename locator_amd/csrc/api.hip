@@ -81,8 +81,11 @@ extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
         if (rc__) return rc__; \
     } while (0)
 
+extern "C" float* loc_workspace_bn4(const loc_net* net) { return carve(&net->d, net->ws).bn4; }
+
 extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                              float* loss_out, void* ev_l1b0, void* ev_l1b1, void* stream) {
+                              float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
+                              void* ev_l1b1, void* stream) {
     const loc_dims* d = &net->d;
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_train_step: n_b=%d out of 1..32", n_b); return -1; }
     const bool use_drop = net->drop_p > 0.f;
@@ -100,8 +103,9 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     const float* at = net->alpha_tab;
     const int atl = net->alpha_tab_len;
 
-    TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
-                           P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
+    if (!bn_ready)
+        TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
+                               P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
     {
         const bool dr = use_drop && npre == 1;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
@@ -112,15 +116,33 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
                                        P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, rows,
                                        net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
+        // the hidden-layer dW/Adam launch only needs what the fused kernel left behind, the layer-1 backward
+        // only needs dz of layer 1: run them concurrently when a side stream is provided
+        const bool fork = net->side_stream && net->ev_fork && net->ev_join;
+        void* dw_stream = stream;
+        if (fork) {
+            hipError_t e = hipEventRecord((hipEvent_t)net->ev_fork, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)net->side_stream, (hipEvent_t)net->ev_fork, 0);
+            if (e != hipSuccess) { loc_set_error("fork to side stream: %s", hipGetErrorString(e)); return (int)e; }
+            dw_stream = net->side_stream;
+        }
         TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
                               net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl, net->lr,
-                              net->t_base, t_off, stream));
+                              net->t_base, t_off, dw_stream));
+        if (fork) {
+            hipError_t e = hipEventRecord((hipEvent_t)net->ev_join, (hipStream_t)net->side_stream);
+            if (e != hipSuccess) { loc_set_error("side stream record: %s", hipGetErrorString(e)); return (int)e; }
+        }
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
         TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
                                  V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,
                                  V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
-                                 net->t_base, t_off, net->l1_bwd_grid, stream));
+                                 net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4, stream));
         if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+        if (fork) {
+            hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)net->ev_join, 0);
+            if (e != hipSuccess) { loc_set_error("join side stream: %s", hipGetErrorString(e)); return (int)e; }
+        }
         return 0;
     }
     for (int l = 2; l <= L; ++l) {
@@ -151,7 +173,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
                              P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
                              P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
-                             net->l1_bwd_grid, stream));
+                             net->l1_bwd_grid, bn_next_stats, w.bn4, stream));
     if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
     return 0;
 }
@@ -190,6 +212,13 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     return 0;
 }
 
+extern "C" int loc_event_create_notiming(void** ev) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) { loc_set_error("hipEventCreateWithFlags: %s", hipGetErrorString(rc)); return (int)rc; }
+    *ev = (void*)e;
+    return 0;
+}
 extern "C" int loc_event_create(void** ev) {
     hipEvent_t e;
     hipError_t rc = hipEventCreate(&e);

@@ -53,6 +53,73 @@ __global__ __launch_bounds__(128) void bn_batch_stats_kernel(
     *reinterpret_cast<f32x4*>(out4 + 3 * (int64_t)Kp + k0) = o_rs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BN batch statistics for EVERY minibatch of an epoch in one launch: they depend only on the genotype
+// matrix and the epoch's permutation, not on any weight.  Grid (SNP quads, steps).
+// stats_ep[step] = [mean | biased var] (2*Kp floats).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void bn_epoch_stats_kernel(const uint8_t* __restrict__ X, int64_t pitch,
+                                                             const int32_t* __restrict__ rows_all, int batch,
+                                                             int n_last, int n_steps, int K, int Kp,
+                                                             float* __restrict__ stats_ep) {
+    const int k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int step = blockIdx.y;
+    if (k0 >= Kp) return;
+    const int n_b = step == n_steps - 1 ? n_last : batch;
+    const int32_t* rows = rows_all + (int64_t)step * batch;
+    int s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int b = 0; b < n_b; ++b) {
+        uint32_t v = *reinterpret_cast<const uint32_t*>(X + (int64_t)rows[b] * pitch + k0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int x = (v >> (8 * c)) & 255;
+            s[c] += x;
+            ss[c] += x * x;
+        }
+    }
+    f32x4 mu = {0, 0, 0, 0}, var = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (k0 + c < K) {
+            mu[c] = (float)s[c] / (float)n_b;
+            var[c] = (float)(n_b * ss[c] - s[c] * s[c]) / (float)(n_b * n_b);
+        }
+    }
+    float* o = stats_ep + (int64_t)step * 2 * Kp;
+    *reinterpret_cast<f32x4*>(o + k0) = mu;
+    *reinterpret_cast<f32x4*>(o + Kp + k0) = var;
+}
+
+// Moving-statistics recurrence over the epoch's steps (same order and arithmetic as the per-step
+// update) and bn4 = [scale|shift|mean|rstd] for step 0 from the current gamma/beta.
+__global__ void bn_epoch_finish_kernel(int K, int Kp, int n_steps, const float* __restrict__ stats_ep,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                       float* __restrict__ bn4) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kp) return;
+    float scale = 0.f, shift = 0.f, mean0 = 0.f, rstd0 = 0.f;
+    if (k < K) {
+        float mm = mov_mean[k], mv = mov_var[k];
+        for (int j = 0; j < n_steps; ++j) {
+            const float mu = stats_ep[(int64_t)j * 2 * Kp + k], var = stats_ep[(int64_t)j * 2 * Kp + Kp + k];
+            mm = mm * BN_MOMENTUM + mu * (1.0f - BN_MOMENTUM);
+            mv = mv * BN_MOMENTUM + var * (1.0f - BN_MOMENTUM);
+        }
+        mov_mean[k] = mm;
+        mov_var[k] = mv;
+        mean0 = stats_ep[k];
+        rstd0 = 1.0f / sqrtf(stats_ep[Kp + k] + BN_EPS);
+        scale = gamma[k] * rstd0;
+        shift = beta[k] - mean0 * scale;
+    }
+    bn4[k] = scale;
+    bn4[Kp + k] = shift;
+    bn4[2 * (int64_t)Kp + k] = mean0;
+    bn4[3 * (int64_t)Kp + k] = rstd0;
+}
+
 __global__ void bn_infer_scale_shift_kernel(int K, int Kp, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, const float* __restrict__ mov_mean,
                                             const float* __restrict__ mov_var, float* __restrict__ out4) {
@@ -398,7 +465,8 @@ __global__ void l1_gamma_beta_adam_kernel(int K, const float* __restrict__ gbs, 
                                           float* __restrict__ v_gamma, float* __restrict__ m_beta,
                                           float* __restrict__ v_beta, const float* __restrict__ alpha_tab,
                                           int alpha_tab_len, const float* __restrict__ lr,
-                                          const int* __restrict__ t_base, int t_off) {
+                                          const int* __restrict__ t_base, int t_off, int Kp,
+                                          const float* __restrict__ next_stats, float* __restrict__ bn4) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
@@ -410,6 +478,14 @@ __global__ void l1_gamma_beta_adam_kernel(int K, const float* __restrict__ gbs, 
     wv = beta[k]; mv = m_beta[k]; vv = v_beta[k];
     adam_update(wv, mv, vv, db, alpha);
     beta[k] = wv; m_beta[k] = mv; v_beta[k] = vv;
+    if (next_stats) {   // the next minibatch's [scale|shift|mean|rstd] from its precomputed batch statistics
+        const float g = gamma[k], mu = next_stats[k], rstd = 1.0f / sqrtf(next_stats[Kp + k] + BN_EPS);
+        const float sc = g * rstd;
+        bn4[k] = sc;
+        bn4[Kp + k] = wv - mu * sc;
+        bn4[2 * (int64_t)Kp + k] = mu;
+        bn4[3 * (int64_t)Kp + k] = rstd;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,6 +520,22 @@ extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_bn_batch_stats: n_b=%d out of 1..32", n_b); return -1; }
     hipLaunchKernelGGL(bn_batch_stats_kernel, dim3((Kp / 4 + 127) / 128), dim3(128), 0, (hipStream_t)stream, X,
                        x_pitch, rows, n_b, K, Kp, gamma, beta, mov_mean, mov_var, out4);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last,
+                                  int n_steps, int K, int Kp, const float* gamma, const float* beta,
+                                  float* mov_mean, float* mov_var, float* stats_ep, float* bn4, void* stream) {
+    if (batch < 1 || batch > LOC_ROWS || n_last < 1 || n_last > batch || n_steps < 1) {
+        loc_set_error("loc_bn_epoch_stats: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
+        return -1;
+    }
+    hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
+                       X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
+    LOC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_epoch_finish_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, Kp,
+                       n_steps, stats_ep, gamma, beta, mov_mean, mov_var, bn4);
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -486,7 +578,8 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                                     float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
                                     float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
                                     float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
-                                    const int* t_base, int t_off, int grid, void* stream) {
+                                    const int* t_base, int t_off, int grid, const float* bn_next_stats,
+                                    float* bn4_out, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..32", n_b); return -1; }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
@@ -508,7 +601,7 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
     LOC_CHECK_LAUNCH();
     hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
                        gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,
-                       t_base, t_off);
+                       t_base, t_off, d->Kp, bn_next_stats, bn4_out);
     LOC_CHECK_LAUNCH();
     return 0;
 }

@@ -9,6 +9,8 @@
 // sync by the Adam kernel), contracting on the vector ALU (R rows is far below an MFMA tile).  The
 // row-reducing work — dW, db and Adam for all hidden layers and the heads, and the batch loss — runs
 // afterwards in ONE wide launch (stack_dw_all_kernel), one workgroup per 32x32 weight tile.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define SF_THREADS 512
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
     int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
-    float* __restrict__ yhat, float* __restrict__ dist) {
+    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride) {
     constexpr int Hp = NHT * 32;
     constexpr int C4 = Hp / 4;               // float4 columns per weight row
     constexpr int KG = SF_THREADS / C4;      // k-groups
@@ -36,8 +38,12 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     __shared__ __attribute__((aligned(16))) float part[KG][R][Hp];     // per-k-group partial sums
     __shared__ float hs[R][8];
 
+    // xcd_stride > 1: only every xcd_stride-th workgroup works, so (with the observed block -> XCD b % 8
+    // dispatch) all row groups share ONE XCD's L2 and each weight line crosses the fabric once.  Pure
+    // speed hint: results do not depend on where workgroups land.
+    if (xcd_stride > 1 && (blockIdx.x % xcd_stride) != 0) return;
     const int t = threadIdx.x, c4 = t % C4, kq = t / C4;
-    const int r0 = blockIdx.x * R;
+    const int r0 = (xcd_stride > 1 ? blockIdx.x / xcd_stride : blockIdx.x) * R;
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
 
     // rows of this block: input of layer 2
@@ -408,15 +414,26 @@ extern "C" int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_h
 
 constexpr int SF_R = 2;   // batch rows per workgroup -> 16 workgroups per 32-row block
 
+static int sf_xcd_stride() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LOC_STACK_XCD_STRIDE");
+        v = e ? atoi(e) : 8;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
                                           const float* wa, const float* ba, const float* wb, const float* bb,
                                           const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
                                           const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
                                           float* head_out, void* stream) {
+    const int xs = sf_xcd_stride();
 #define LAUNCH(N)                                                                                                  \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3(32 / SF_R), dim3(SF_THREADS), 0,                  \
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3(32 / SF_R * xs), dim3(SF_THREADS), 0,             \
                        (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,  \
-                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr);
+                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -427,10 +444,12 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
                                       const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
                                       const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
     const int nblk = (n_b + SF_R - 1) / SF_R;
+    const int xs = sf_xcd_stride();
 #define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3(nblk), dim3(SF_THREADS), 0, (hipStream_t)stream, \
-                       a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb, (const uint8_t*)nullptr, 1.f, L, 0, n_b, \
-                       rows, Y, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, yhat, dist);
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3(nblk * xs), dim3(SF_THREADS), 0,                \
+                       (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
+                       (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
+                       (float*)nullptr, (float*)nullptr, yhat, dist, xs);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();

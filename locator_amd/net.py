@@ -79,6 +79,16 @@ class LocatorNet:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
+        # side stream + fork/join events: hidden-layer dW/Adam overlaps the layer-1 backward
+        # (measured: the persistent layer-1 backward occupies every CU's register file, so the side launch
+        #  queues behind it and the join then costs more than the serial 10 us — off unless LOC_SIDE_STREAM=1)
+        import os
+        self.side_stream = (torch.cuda.Stream(device=dev)
+                            if self.use_fused and os.environ.get("LOC_SIDE_STREAM") == "1" else None)
+        self._ev_fork, self._ev_join = C.c_void_p(), C.c_void_p()
+        if self.side_stream is not None:
+            _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_fork)), "event")
+            _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_join)), "event")
         self._net = None
         self.init_weights()
 
@@ -93,6 +103,8 @@ class LocatorNet:
         n.drop_p = self.drop_p
         n.wht = self.wht.data_ptr() if self.wht is not None else None
         n.ws = self.ws.data_ptr()
+        if self.side_stream is not None:
+            n.side_stream, n.ev_fork, n.ev_join = self.side_stream.cuda_stream, self._ev_fork, self._ev_join
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         self._net = n
         return n
@@ -190,12 +202,25 @@ class LocatorNet:
         self.refresh_transposed()
 
     # ------------------------------------------------------------------ ops
-    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None):
+    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None):
         """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
-        mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view."""
+        mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view.
+        bn_ready / bn_next: epoch-level BN statistics (see epoch_bn_stats)."""
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_train_step(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
-                                           _ptr(loss_out), ev0, ev1, _stream()), "loc_train_step")
+                                           _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next), ev0, ev1,
+                                           _stream()), "loc_train_step")
+
+    def epoch_bn_stats(self, rows_all, batch, n_last, n_steps, stats_ep):
+        """BN batch statistics of every minibatch of the epoch in one launch, the epoch's moving-statistics
+        updates, and step 0's scale/shift (loc_bn_epoch_stats)."""
+        net = self._net or self.cnet()
+        d, lay, P = self.d, self.lay, self.params.data_ptr()
+        _lib.check(self.lib.loc_bn_epoch_stats(self.X.data_ptr(), self.X.stride(0), _ptr(rows_all), int(batch),
+                                               int(n_last), int(n_steps), d.K, d.Kp, P + 4 * lay.gamma,
+                                               P + 4 * lay.beta, P + 4 * lay.mov_mean, P + 4 * lay.mov_var,
+                                               _ptr(stats_ep), self.lib.loc_workspace_bn4(C.byref(net)), _stream()),
+                   "loc_bn_epoch_stats")
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""

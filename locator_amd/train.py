@@ -83,6 +83,8 @@ class EpochRunner:
         self.stats = torch.zeros(self.steps + max(self.n_val, 1), dtype=torch.float32, device=dev)
         self.stats_host = torch.empty_like(self.stats, device="cpu").pin_memory()
         self.val_yhat = torch.zeros((max(self.n_val, 1), 2), dtype=torch.float32, device=dev)
+        # [steps][mean | var][Kp]: BN batch statistics of every minibatch of the epoch (one launch per epoch)
+        self.stats_ep = torch.zeros(self.steps * 2 * net.d.Kp, dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self.graph = None
         self.epochs_run = 0
@@ -91,11 +93,15 @@ class EpochRunner:
 
     def enqueue(self, ev=None):
         net = self.net
+        sz = 2 * net.d.Kp
+        net.epoch_bn_stats(self.perm_dev, self.batch, int(self.step_sizes[-1]), self.steps, self.stats_ep)
         for j in range(self.steps):
             nb = int(self.step_sizes[j])
             mask = self.masks[j * self.mask_stride:] if self.masks is not None else None
             e0, e1 = (ev[j] if ev is not None else (None, None))
-            net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1)
+            nxt = self.stats_ep[(j + 1) * sz:] if j + 1 < self.steps else None
+            net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
+                           bn_ready=True, bn_next=nxt)
         if self.n_val:
             net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
         net.t_base_t.add_(self.steps)
