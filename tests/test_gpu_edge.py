@@ -1,0 +1,114 @@
+"""Edge cases on the GPU path: shapes the reference tolerates (or crashes on) that the HIP path must
+handle or reject loudly — odd layer counts, widths that are not multiples of 32, fewer SNPs than a
+tile, training sets smaller than a batch, batch sizes below 32, no samples to predict."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import locator_oracle as O
+from tests.gpu_util import build_net, make_problem, maxerr, params_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,width,nlayers,batch,n_train", [
+    (20, 8, 2, 32, 50),        # K < one 32-SNP tile, tiny width (padded to 32), minimum depth
+    (100, 100, 7, 32, 40),     # odd depth: 3 layers before dropout, 4 after; width padded 100 -> 128
+    (300, 64, 4, 7, 30),       # --batch_size 7: five steps per epoch, last batch of 2
+    (64, 256, 3, 32, 12),      # training set smaller than one batch
+    (257, 33, 5, 16, 33),      # width 33 -> 64, K = 8 tiles + 1 SNP, last batch of 1
+])
+def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
+    """3 epochs of fit (eager epoch 0, captured graph afterwards) vs oracle.fit with the same init,
+    permutations and the device's dropout masks.  Tolerance 5e-4 on per-epoch losses."""
+    from locator_amd.train import EpochRunner
+    n_val = 9
+    x, y, p, rng = make_problem(n_train + n_val, K, width, nlayers, seed=K + width)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + n_val)
+    net = build_net(x, y, p, drop_p=0.25, seed=5)
+    runner = EpochRunner(net, tr, va, batch, use_graph=True)
+    perms = [np.random.default_rng(e).permutation(n_train) for e in range(3)]
+    masks, hist = [], {"loss": [], "val_loss": []}
+    for e in range(3):
+        l, vl = runner.run_epoch(perms[e])
+        masks.append(runner.masks.cpu().numpy().reshape(runner.steps, 32, net.d.Hp).copy())
+        hist["loss"].append(l)
+        hist["val_loss"].append(vl)
+    pref = O.copy_params(p)
+    href, _ = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=batch, max_epochs=3, patience=100, drop_p=0.25,
+                    perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s, :nb, :width])
+    assert maxerr(hist["loss"], href["loss"]) < 5e-4, (hist["loss"], href["loss"])
+    assert maxerr(hist["val_loss"], href["val_loss"]) < 5e-4
+    errs = params_err(net.export_params(), pref)
+    assert max(errs.values()) < 1e-4, errs
+    # padding of the width / SNP axes stayed exactly zero through training
+    d, lay = net.d, net.lay
+    flat = net.params.cpu().numpy()
+    wh = flat[lay.wh:lay.wh + (d.L - 1) * d.Hp * d.Hp].reshape(d.L - 1, d.Hp, d.Hp)
+    assert not wh[:, d.H:, :].any() and not wh[:, :, d.H:].any()
+    assert not flat[lay.b1 + d.H:lay.b1 + d.Hp].any() and not flat[lay.gamma + d.K:lay.gamma + d.Kp].any()
+
+
+def test_no_dropout_and_dropout_on_first_layer():
+    """--dropout_prop 0 (no mask anywhere) and nlayers 2/3 (Dropout directly after the layer-1 Dense)."""
+    for nlayers, drop_p in [(2, 0.5), (3, 0.25), (4, 0.0)]:
+        x, y, p, rng = make_problem(48, 90, 64, nlayers, seed=nlayers)
+        net = build_net(x, y, p, drop_p=drop_p)
+        idx = rng.choice(48, 32, replace=False)
+        mask_np = (rng.random((32, 64)) >= drop_p).astype(np.uint8)
+        loss = torch.zeros(1, device="cuda")
+        rows = torch.from_numpy(idx.astype(np.int32)).cuda()
+        net.train_step(rows, 32, 1, torch.from_numpy(mask_np).cuda() if drop_p > 0 else None, loss)
+        torch.cuda.synchronize()
+        pr = O.copy_params(p)
+        m, v = O.zeros_like_trainable(pr), O.zeros_like_trainable(pr)
+        ref = O.train_step(pr, m, v, 1, 1e-3, x[idx], y[idx], mask_np, drop_p)
+        assert abs(loss.item() - ref) < 2e-5
+        assert max(params_err(net.export_params(), pr).values()) < 1e-5, nlayers
+
+
+def test_predict_zero_rows_and_non_multiple_of_32():
+    x, y, p, rng = make_problem(70, 128, 64, 4)
+    net = build_net(x, y, p)
+    yhat = torch.zeros((70, 2), device="cuda")
+    net.predict_rows(torch.arange(70, dtype=torch.int32, device="cuda"), 0, yhat)      # no-op, no error
+    net.predict_rows(torch.arange(70, dtype=torch.int32, device="cuda"), 70, yhat)
+    torch.cuda.synchronize()
+    assert maxerr(yhat.cpu().numpy(), O.predict(p, x)) < 2e-5
+
+
+def test_cli_without_samples_to_predict(tmp_path):
+    """Every sample has a known location: the reference would call model.predict on an empty array
+    (SURVEY Q11); here predlocs.txt is written with the header only and the run completes."""
+    import os
+    import pandas as pd
+    from locator_amd import locator as L
+    rng = np.random.default_rng(0)
+    n, K = 60, 200
+    af = rng.uniform(0.1, 0.9, K)
+    g = rng.binomial(2, af, (n, K))
+    mat = tmp_path / "m.txt"
+    df = pd.DataFrame(g, columns=[f"s{i}" for i in range(K)])
+    df.insert(0, "sampleID", [f"id{i}" for i in range(n)])
+    df.to_csv(mat, sep="\t", index=False)
+    sd = tmp_path / "s.txt"
+    pd.DataFrame({"sampleID": [f"id{i}" for i in range(n)], "x": rng.uniform(0, 10, n),
+                  "y": rng.uniform(0, 10, n)}).to_csv(sd, sep="\t", index=False)
+    out = str(tmp_path / "o")
+    assert L.main(["--matrix", str(mat), "--sample_data", str(sd), "--out", out, "--seed", "3", "--max_epochs", "3",
+                   "--patience", "3", "--keras_verbose", "0", "--width", "32", "--nlayers", "4"]) == 0
+    assert open(out + "_predlocs.txt").read().strip() == "x,y,sampleID"
+    assert len(pd.read_csv(out + "_history.txt", sep="\t")) == 3
+    assert os.path.exists(out + "_fitplot.pdf")
+
+
+def test_unsupported_configurations_are_rejected_with_messages():
+    from locator_amd import _lib
+    from locator_amd.net import LocatorNet, upload_genotypes
+    x = np.zeros((8, 40), np.uint8)
+    X = upload_genotypes(x)
+    Y = torch.zeros((8, 2), device="cuda")
+    with pytest.raises(_lib.LocatorHipError, match="nlayers"):
+        LocatorNet(X, Y, 40, 64, 1)
+    with pytest.raises(_lib.LocatorHipError, match="width"):
+        LocatorNet(X, Y, 40, 600, 4)
