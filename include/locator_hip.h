@@ -95,6 +95,10 @@ typedef struct loc_net {
     void* side_stream;
     void* ev_fork;
     void* ev_join;
+    /* optional split-K hidden stack (LOC_STACK_SPLIT=4): zero-initialised hand-off buffer of
+     * loc_stack_split_bytes(Hp) bytes and a 1-int error word (set if a bounded spin times out) */
+    void* gran;
+    int* stack_err;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
 } loc_net;
@@ -207,6 +211,19 @@ int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const flo
                       float* WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba, int64_t off_wb,
                       int64_t off_bb, float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
                       const int* t_base, int t_off, void* stream);
+
+/* Experimental split-K form of loc_stack_forward_backward: 4 workgroups per row group exchange partial sums
+ * through tagged 8-byte granules (agent-scope relaxed atomics; no placement assumption; bounded spins). */
+/* Debug: device buffer of >= 256 int64 that the fused stack's workgroup 0 fills with wall_clock64() stamps. */
+int loc_debug_set_buffer(void* p);
+int loc_stack_split_enabled(int Hp);
+int64_t loc_stack_split_bytes(int Hp);
+int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
+                                     const float* wa, const float* ba, const float* wb, const float* bb,
+                                     const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
+                                     const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
+                                     float* head_out, void* granules, const int* t_base, int t_off, int* err,
+                                     void* stream);
 
 /* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).

@@ -33,7 +33,7 @@ class Layout(C.Structure):
 class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
-                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
+                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("gran", vp), ("stack_err", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -75,6 +75,11 @@ SIGNATURES = {
     "loc_stack_dw_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                     C.c_int, vp, vp, C.c_int, vp]),
+    "loc_debug_set_buffer": (C.c_int, [vp]),
+    "loc_stack_split_enabled": (C.c_int, [C.c_int]),
+    "loc_stack_split_bytes": (C.c_int64, [C.c_int]),
+    "loc_stack_forward_backward_split": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
     "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),

@@ -113,9 +113,16 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     }
     if (net->wht && loc_stack_fused_supported(Hp)) {
         // fused row-parallel hidden stack: 2 launches instead of 2(L-1)+2
-        TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
-                                       P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, rows,
-                                       net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
+        if (net->gran && net->stack_err && loc_stack_split_enabled(Hp)) {
+            TRY(loc_stack_forward_backward_split(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
+                                                 P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre,
+                                                 n_b, rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, net->gran,
+                                                 net->t_base, t_off, net->stack_err, stream));
+        } else {
+            TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
+                                           P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b,
+                                           rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
+        }
         // the hidden-layer dW/Adam launch only needs what the fused kernel left behind, the layer-1 backward
         // only needs dz of layer 1: run them concurrently when a side stream is provided
         const bool fork = net->side_stream && net->ev_fork && net->ev_join;

@@ -89,6 +89,11 @@ class LocatorNet:
         if self.side_stream is not None:
             _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_fork)), "event")
             _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_join)), "event")
+        # split-K hidden stack (experimental, LOC_STACK_SPLIT=4): zeroed hand-off buffer + error word
+        self.gran = self.stack_err = None
+        if self.use_fused and self.lib.loc_stack_split_enabled(self.d.Hp):
+            self.gran = torch.zeros(self.lib.loc_stack_split_bytes(self.d.Hp), dtype=torch.uint8, device=dev)
+            self.stack_err = torch.zeros(1, dtype=torch.int32, device=dev)
         self._net = None
         self.init_weights()
 
@@ -105,6 +110,8 @@ class LocatorNet:
         n.ws = self.ws.data_ptr()
         if self.side_stream is not None:
             n.side_stream, n.ev_fork, n.ev_join = self.side_stream.cuda_stream, self._ev_fork, self._ev_join
+        if self.gran is not None:
+            n.gran, n.stack_err = self.gran.data_ptr(), self.stack_err.data_ptr()
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         self._net = n
         return n
