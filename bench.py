@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing)")
+    ap.add_argument("--device-index", type=int, default=None,
+                    help="testing: put every rank on this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +104,16 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+    if args.device_index is not None:
+        local = args.device_index
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from locator_amd import _lib
     from locator_amd.net import LocatorNet, gather_columns, upload_genotypes
@@ -156,7 +164,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
