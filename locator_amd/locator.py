@@ -17,7 +17,7 @@ Deliberate, documented deviations:
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 32 rows (the reference default) and --nlayers must be >= 2;
-  * extra flags --gpus / --no_graph / --net_seed (recorded at the end of params.json).
+  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed (recorded at the end of params.json).
 """
 from __future__ import annotations
 
@@ -78,6 +78,8 @@ def build_parser():
     # --- additions of this implementation (kept last so the reference's keys keep their order)
     p.add_argument("--gpus", default=None, type=int,
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
+    p.add_argument("--fits_per_gpu", default=2, type=int,
+                   help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
     p.add_argument("--net_seed", default=None, type=int,
                    help="seed of weight init / shuffling / dropout (the reference leaves these unseeded); "
@@ -441,9 +443,13 @@ def main(argv=None):
 
     if args.windows:
         units = _window_units(samples)
-        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus)
+        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu)
         for r in results:                       # fitplot is overwritten per window in the reference
-            print(f"{r['name']}: run time {r['seconds'] / 60:.2f} minutes")
+            if "error" in r:
+                print(f"{r['name']}: FAILED: {r['error']}")
+            else:
+                print(f"{r['name']}: run time {r['seconds'] / 60:.2f} minutes")
+        results = [r for r in results if "error" not in r]
         if results and args.plot_history:
             plot_history(_H(results[-1]["history"]), results[-1]["dists"])
     elif not args.bootstrap and not args.jacknife:
@@ -459,8 +465,10 @@ def main(argv=None):
         shared = dict(traingen=np.ascontiguousarray(traingen), testgen=np.ascontiguousarray(testgen),
                       predgen=np.ascontiguousarray(predgen), trainlocs=trainlocs, testlocs=testlocs, pred=pred,
                       samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, out=args.out)
-        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, shared=shared)
+        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, shared=shared,
+                                       fits_per_gpu=args.fits_per_gpu)
         # {out}_history.txt / fitplot are overwritten by every replicate in the reference: last one wins
+        results = [r for r in results if "error" not in r]
         if results:
             import pandas as pd
             pd.DataFrame(results[-1]["history"]).to_csv(args.out + "_history.txt", sep="\t", index=False)

@@ -56,14 +56,19 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print):
+def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print, fits_per_gpu=1):
     """Run every unit once; returns the result records in unit order.
 
-    units    list of dicts (small per-unit data; window units carry their own genotype slices)
-    shared   dict of data common to all units (sent to each worker once)
-    prepare  optional per-unit hook run in the worker before fit_fn (e.g. column resampling)"""
+    units         list of dicts (small per-unit data; window units carry their own genotype slices)
+    shared        dict of data common to all units (sent to each worker once)
+    prepare       optional per-unit hook run in the worker before fit_fn (e.g. column resampling)
+    fits_per_gpu  worker processes per GPU.  A single fit alternates between an HBM-bound phase (layer 1)
+                  and a latency-bound phase (hidden stack, 16 CUs); two fits on one GPU interleave them:
+                  measured 170k vs 129k samples/s aggregate on the 1000 x 100k workload (1.32x), no further
+                  gain from a third."""
     n_vis = visible_gpus()
-    n = max(1, min(n_gpus or n_vis, max(n_vis, 1), len(units)))
+    n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
+    n = max(1, min(n_g * max(1, int(fits_per_gpu)), len(units)))
     out = [None] * len(units)
     if n <= 1:
         for i, u in enumerate(units):
@@ -78,8 +83,8 @@ def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=p
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     tasks, results = ctx.Queue(maxsize=2 * n), ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(g, fit_fn, shared, args, prepare, tasks, results), daemon=True)
-             for g in range(n)]
+    procs = [ctx.Process(target=_worker, args=(w % n_g, fit_fn, shared, args, prepare, tasks, results), daemon=True)
+             for w in range(n)]
     for p in procs:
         p.start()
     sent = got = 0
