@@ -239,3 +239,36 @@ def test_run_units_distributed_gloo_world2_matches_single_process():
     for rank in (0, 1):
         assert [v for _, _, v in got[rank]] == [r["value"] for r in single]
         assert [g for _, g, _ in got[rank]] == [i % 2 for i in range(7)]
+
+
+# ------------------------------------------------------------------ replicate summarisation
+def test_summarize_centroid_and_kernel_peak(tmp_path):
+    import pandas as pd
+    from sklearn.neighbors import KernelDensity
+    from locator_amd import summarize as S
+    rng = np.random.default_rng(0)
+    ids = [f"s{i}" for i in range(5)]
+    truth = rng.uniform(0, 50, (5, 2))
+    preds = []
+    for b in range(12):
+        p = truth + rng.normal(0, 0.3, (5, 2))
+        if b == 3:
+            p[0] += 25.0                       # one outlier replicate for s0
+        preds.append(p)
+        pd.DataFrame({"x": p[:, 0], "y": p[:, 1], "sampleID": ids}).to_csv(tmp_path / f"run_boot{b}_predlocs.txt",
+                                                                          index=False)
+    sd = tmp_path / "samples.txt"
+    pd.DataFrame({"sampleID": ids, "x": truth[:, 0], "y": truth[:, 1]}).to_csv(sd, sep="\t", index=False)
+    bp = S.summarize(str(tmp_path), str(sd), str(tmp_path / "out"), silence=True)
+    assert list(bp.columns) == ["sampleID", "x", "y", "kd_x", "kd_y", "gc_x", "gc_y"] and len(bp) == 5
+    P = np.array(preds)                        # (12, 5, 2)
+    assert np.allclose(bp[["gc_x", "gc_y"]].to_numpy(), P.mean(0))
+    for i in range(5):                         # same point as sklearn's KernelDensity picks (the reference's estimator)
+        kd = KernelDensity(kernel="gaussian", bandwidth=0.2).fit(P[:, i, :])
+        j = int(np.argmax(kd.score_samples(P[:, i, :])))
+        assert np.allclose(bp.loc[i, ["kd_x", "kd_y"]].to_numpy(dtype=float), P[j, i, :])
+    # the density peak ignores the outlier, the centroid does not
+    assert np.hypot(bp.kd_x[0] - truth[0, 0], bp.kd_y[0] - truth[0, 1]) < 1.0
+    assert np.hypot(bp.gc_x[0] - truth[0, 0], bp.gc_y[0] - truth[0, 1]) > 2.0
+    out = pd.read_csv(str(tmp_path / "out") + "_centroids.txt", sep="\t")
+    assert list(out.columns) == list(bp.columns)
