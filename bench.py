@@ -16,7 +16,8 @@ is used only for the barrier and the max-over-ranks of the elapsed time.  scalin
 
 The JSON line also carries
   roofline      the dominant kernel (l1_bwd_adam: fused layer-1 backward + Adam), algorithmic bytes per
-                launch / its mean duration from HIP events recorded on the launch stream, vs 8 TB/s HBM
+                launch / its mean duration from HIP events recorded on the launch stream immediately before and
+                after that kernel, vs 8 TB/s HBM; `traffic` = PMC-measured bytes (profiles/r01_pmc_traffic.json)
   cpu_baseline  the NumPy fp32 port of the same step (oracle/) timed on this box's host cores on a
                 bounded sample of the same workload.
 """

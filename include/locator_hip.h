@@ -158,13 +158,14 @@ int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats
  * ([mean|var] of the NEXT minibatch, from loc_bn_epoch_stats) is non-NULL that kernel also writes the next
- * step's [scale|shift|mean|rstd] to bn4_out from the just-updated gamma/beta. */
+ * step's [scale|shift|mean|rstd] to bn4_out from the just-updated gamma/beta.  ev_after_main: optional
+ * hipEvent_t recorded between the main kernel and the trailing per-SNP kernel (kernel timing). */
 int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                          const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
                          float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
                          float* b1, float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab,
                          int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid,
-                         const float* bn_next_stats, float* bn4_out, void* stream);
+                         const float* bn_next_stats, float* bn4_out, void* ev_after_main, void* stream);
 
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,

@@ -56,7 +56,7 @@ SIGNATURES = {
                                  C.c_float, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
-                                       vp]),
+                                       vp, vp]),
     "loc_bn_epoch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                      vp, vp, vp]),
     "loc_workspace_bn4": (vp, [C.POINTER(Net)]),

@@ -144,8 +144,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
                                  V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,
                                  V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
-                                 net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4, stream));
-        if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+                                 net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, stream));
         if (fork) {
             hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)net->ev_join, 0);
             if (e != hipSuccess) { loc_set_error("join side stream: %s", hipGetErrorString(e)); return (int)e; }
@@ -180,8 +179,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
                              P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
                              P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
-                             net->l1_bwd_grid, bn_next_stats, w.bn4, stream));
-    if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+                             net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, stream));
     return 0;
 }
 

@@ -579,7 +579,7 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                                     float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
                                     float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
                                     const int* t_base, int t_off, int grid, const float* bn_next_stats,
-                                    float* bn4_out, void* stream) {
+                                    float* bn4_out, void* ev_after_main, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..32", n_b); return -1; }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
@@ -599,6 +599,7 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
     NHT_SWITCH(nht, LAUNCH_BWD)
 #undef LAUNCH_BWD
     LOC_CHECK_LAUNCH();
+    if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
                        gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,
                        t_base, t_off, d->Kp, bn_next_stats, bn4_out);
