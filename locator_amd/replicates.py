@@ -37,8 +37,11 @@ def _run_one(fit_fn, unit, shared, args, device):
 
 def _worker(gpu, fit_fn, shared, args, prepare, tasks, results):
     import torch
-    torch.cuda.set_device(gpu)
-    device = f"cuda:{gpu}"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(gpu)
+        device = f"cuda:{gpu}"
+    else:               # scheduler tests on CPU; a real fit_fn raises on this device (no CPU fallback)
+        device = "cpu"
     while True:
         item = tasks.get()
         if item is None:

@@ -203,6 +203,21 @@ def test_run_units_sequential_order_and_failure_isolation():
         assert res[i]["value"] == (sum(range(i + 3)) + 10.0) * (i + 1) and res[i]["args_out"] == "stem"
 
 
+def test_run_units_spawned_workers_dynamic_queue_on_cpu():
+    """The multi-worker path (spawned processes + bounded task queue + result queue): results come back in
+    unit order whatever the completion order, a failing unit is reported and its siblings still run."""
+    units = _units(9)
+    units[4]["explode"] = True
+    logs = []
+    res = R.run_units(units, _Args(), _fake_fit, n_gpus=1, shared={"shared_bias": 2.0}, log=logs.append,
+                      fits_per_gpu=3)
+    assert [r["unit_index"] for r in res] == list(range(9))
+    assert "error" in res[4] and sum("FAILED" in l for l in logs) == 1
+    for i in range(9):
+        if i != 4:
+            assert res[i]["value"] == (sum(range(i + 3)) + 2.0) * (i + 1)
+
+
 def test_shard_static_partitions_units():
     for n, w in [(10, 4), (3, 8), (257, 8), (0, 2)]:
         parts = [R.shard_static(n, r, w) for r in range(w)]
