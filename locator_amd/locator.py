@@ -435,11 +435,26 @@ def main(argv=None):
     _setup(argv)
     from . import replicates
 
-    genotypes, samples = load_genotypes()
-    sample_data, locs = sort_samples(samples, genotypes)
-    meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
-    ac = filter_snps(genotypes)
-    train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
+    if args.windows and not args.impute_missing and args.max_SNPs is None:
+        # The reference loads and filters the WHOLE store here (locator.py:508-516) and then discards the
+        # result: the window loop re-slices, re-filters and re-splits.  All that survives is the state of
+        # the global NumPy stream, and without --impute_missing / --max_SNPs the only draw is the split's
+        # np.random.choice, which depends on the sample file alone.  Make that draw, skip the 5.7 GB read.
+        print("reading zarr")
+        callset = G.open_group(args.zarr, mode="r")
+        samples = np.asarray(callset["samples"][:])
+
+        class _Shape:
+            shape = tuple(callset["calldata/GT"].shape)
+        sample_data, locs = sort_samples(samples, _Shape())
+        meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+        split_indices(locs, args.train_split)
+    else:
+        genotypes, samples = load_genotypes()
+        sample_data, locs = sort_samples(samples, genotypes)
+        meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+        ac = filter_snps(genotypes)
+        train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
 
     if args.windows:
         units = _window_units(samples)
