@@ -430,12 +430,10 @@ def _bootstrap_units(n_sites):
     return units
 
 
-# ------------------------------------------------------------------ main (locator.py:487-749)
-def main(argv=None):
-    _setup(argv)
-    from . import replicates
-
-    if args.windows and not args.impute_missing and args.max_SNPs is None:
+def _prologue(force_full=False):
+    """locator.py:507-516.  Returns (samples, state) where state is None in the windows fast path or the
+    tuple (meanlong, sdlong, meanlat, sdlat, ac, train, test, traingen, testgen, trainlocs, testlocs, pred, predgen)."""
+    if args.windows and not args.impute_missing and args.max_SNPs is None and not force_full:
         # The reference loads and filters the WHOLE store here (locator.py:508-516) and then discards the
         # result: the window loop re-slices, re-filters and re-splits.  All that survives is the state of
         # the global NumPy stream, and without --impute_missing / --max_SNPs the only draw is the split's
@@ -449,12 +447,25 @@ def main(argv=None):
         sample_data, locs = sort_samples(samples, _Shape())
         meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
         split_indices(locs, args.train_split)
-    else:
-        genotypes, samples = load_genotypes()
-        sample_data, locs = sort_samples(samples, genotypes)
-        meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
-        ac = filter_snps(genotypes)
-        train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
+        return samples, None
+    genotypes, samples = load_genotypes()
+    sample_data, locs = sort_samples(samples, genotypes)
+    meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+    ac = filter_snps(genotypes)
+    train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
+    return samples, (meanlong, sdlong, meanlat, sdlat, ac, train, test, traingen, testgen, trainlocs, testlocs,
+                     pred, predgen)
+
+
+# ------------------------------------------------------------------ main (locator.py:487-749)
+def main(argv=None):
+    _setup(argv)
+    from . import replicates
+
+    samples, state = _prologue()
+    if state is not None:
+        (meanlong, sdlong, meanlat, sdlat, ac, train, test, traingen, testgen, trainlocs, testlocs, pred,
+         predgen) = state
 
     if args.windows:
         units = _window_units(samples)

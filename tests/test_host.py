@@ -287,3 +287,25 @@ def test_summarize_centroid_and_kernel_peak(tmp_path):
     assert np.hypot(bp.gc_x[0] - truth[0, 0], bp.gc_y[0] - truth[0, 1]) > 2.0
     out = pd.read_csv(str(tmp_path / "out") + "_centroids.txt", sep="\t")
     assert list(out.columns) == list(bp.columns)
+
+
+def test_windows_fast_prologue_keeps_the_rng_stream(tmp_path, fixture_vcf):
+    """--windows skips the reference's discarded whole-store load (locator.py:508-516); the per-window splits
+    must come out exactly as if it had been done (same global NumPy stream)."""
+    gt, pos, samples = fixture_vcf["calldata/GT"][:3000], fixture_vcf["variants/POS"][:3000], fixture_vcf["samples"]
+    store = str(tmp_path / "w.zarr")
+    G.write_callset_zarr(store, gt, pos, samples, chunk_variants=1024)
+    size = int(pos[-1] // 3 + 1)
+    argv = ["--zarr", store, "--sample_data", SAMPLES, "--out", str(tmp_path / "o"), "--seed", "777", "--windows",
+            "--window_size", str(size)]
+    got = []
+    for force_full in (True, False):
+        L._setup(argv)
+        smp, state = L._prologue(force_full=force_full)
+        assert (state is None) == (not force_full)
+        got.append(L._window_units(smp))
+    assert len(got[0]) == len(got[1]) == 3
+    for a, b in zip(*got):
+        assert a["name"] == b["name"] and np.array_equal(a["pred"], b["pred"])
+        for k in ("traingen", "testgen", "predgen", "trainlocs", "testlocs"):
+            assert np.array_equal(a[k], b[k]), k
