@@ -364,6 +364,8 @@ def _fit_unit(unit, device="cuda:0"):
     from .net import gather_columns, upload_genotypes
     args = unit["args"]
     t1 = time.time()
+    if "window" in unit:
+        _load_window(unit)
     tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
     ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
     key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
@@ -390,32 +392,76 @@ def _fit_unit(unit, device="cuda:0"):
     return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t1}
 
 
-def _window_units(samples):
-    """Host prologue of the window loop, in reference order (locator.py:519-545): everything that reads
-    the zarr store or advances the global NumPy stream happens here, sequentially."""
+def _window_bounds():
     callset = G.open_group(args.zarr, mode="r")
-    gt = callset["calldata/GT"]
     positions = np.array(callset["variants/POS"][:])
     start = int(args.window_start)
     stop = np.max(positions) if args.window_stop is None else int(args.window_stop)
     size = int(args.window_size)
-    units = []
-    for n, i in enumerate(np.arange(start, stop, size)):
-        print(f"\nProcessing window {i}-{i + size}")
+    out = []
+    for i in np.arange(start, stop, size):
         mask = np.logical_and(positions >= i, positions < i + size)
-        a = np.min(np.argwhere(mask))
+        a = np.min(np.argwhere(mask))               # an empty window raises here, as in the reference
         b = np.max(np.argwhere(mask))
+        out.append((int(i), int(size), int(a), int(b)))
+    return out
+
+
+def _window_units(samples, lazy=None):
+    """Host prologue of the window loop, in reference order (locator.py:519-545).
+
+    Everything that advances the global NumPy stream happens here, sequentially.  Without
+    --impute_missing / --max_SNPs the only draw per window is the split's np.random.choice, which depends
+    on the sample file alone — so the splits are drawn up front and the expensive part (zarr slice +
+    filters, ~2 s per 150k-variant window) is deferred to the worker that fits the window
+    (`_load_window`), otherwise the serial prologue would cap multi-GPU scaling.  With either flag the
+    draws depend on the genotypes and the whole prologue runs here, exactly as the reference does."""
+    if lazy is None:
+        lazy = not args.impute_missing and args.max_SNPs is None
+    units = []
+    for n, (i, size, a, b) in enumerate(_window_bounds()):
+        print(f"\nProcessing window {i}-{i + size}")
         print(f"SNPs {a}-{b}")
-        genotypes = np.asarray(gt[a:b, :, :], dtype=np.int8)       # excludes SNP b, as the reference does (Q4)
-        sample_data, locs = sort_samples(samples, genotypes)
+        unit = dict(name=f"window {i}-{i + size - 1}", replicate=n, boot=None, out=f"{args.out}_{i}-{i + size - 1}",
+                    samples=samples)
+        if lazy:
+            class _Shape:
+                shape = (b - a, len(samples), 2)
+            sample_data, locs = sort_samples(samples, _Shape())
+            meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
+            train, test, pred = split_indices(locs, args.train_split)
+            unit.update(window=(a, b), zarr=args.zarr, train=train, test=test, pred=pred, locs=locs,
+                        sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat)
+        else:
+            unit.update(window=(a, b), zarr=args.zarr)
+            _load_window(unit, draw_split=True)
+        units.append(unit)
+    return units
+
+
+def _load_window(unit, draw_split=False):
+    """Slice the store (gt[a:b]: excludes SNP b, as the reference does), filter, and cut the
+    train / validation / prediction rows.  Runs in the worker for lazy units."""
+    if "traingen" in unit:
+        return unit
+    a, b = unit["window"]
+    gt = G.open_group(unit["zarr"], mode="r")["calldata/GT"]
+    genotypes = np.asarray(gt[a:b, :, :], dtype=np.int8)
+    if draw_split:                                   # eager path: reference order sort -> normalise -> filter -> split
+        sample_data, locs = sort_samples(unit["samples"], genotypes)
         meanlong, sdlong, meanlat, sdlat, locs = normalize_locs(locs)
         ac = filter_snps(genotypes)
-        train, test, traingen, testgen, trainlocs, testlocs, pred, predgen = split_train_test(ac, locs)
-        units.append(dict(name=f"window {i}-{i + size - 1}", replicate=n, boot=None, out=f"{args.out}_{i}-{i + size - 1}",
-                          traingen=np.ascontiguousarray(traingen), testgen=np.ascontiguousarray(testgen),
-                          predgen=np.ascontiguousarray(predgen), trainlocs=trainlocs, testlocs=testlocs, pred=pred,
-                          samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat))
-    return units
+        train, test, pred = split_indices(locs, args.train_split)
+        unit.update(sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat)
+    else:
+        ac = G.filter_snps(genotypes, min_mac=unit["args"].min_mac if "args" in unit else args.min_mac, verbose=False)
+        train, test, pred, locs = unit["train"], unit["test"], unit["pred"], unit["locs"]
+    unit.update(traingen=np.ascontiguousarray(np.transpose(ac[:, train])),
+                testgen=np.ascontiguousarray(np.transpose(ac[:, test])),
+                predgen=(np.ascontiguousarray(np.transpose(ac[:, pred])) if len(pred)
+                         else np.zeros((0, ac.shape[0]), ac.dtype)),
+                trainlocs=locs[train], testlocs=locs[test], pred=pred)
+    return unit
 
 
 def _bootstrap_units(n_sites):

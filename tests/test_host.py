@@ -303,7 +303,13 @@ def test_windows_fast_prologue_keeps_the_rng_stream(tmp_path, fixture_vcf):
         L._setup(argv)
         smp, state = L._prologue(force_full=force_full)
         assert (state is None) == (not force_full)
-        got.append(L._window_units(smp))
+        # eager units (parent slices + filters, the reference's order) vs lazy units (splits drawn up front,
+        # slice + filter deferred to the worker)
+        units = L._window_units(smp, lazy=not force_full)
+        if not force_full:
+            assert all("traingen" not in u for u in units)
+            units = [L._load_window(dict(u, args=L.args)) for u in units]
+        got.append(units)
     assert len(got[0]) == len(got[1]) == 3
     for a, b in zip(*got):
         assert a["name"] == b["name"] and np.array_equal(a["pred"], b["pred"])
