@@ -28,7 +28,8 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
     int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
-    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, long long* __restrict__ dbg) {
+    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work,
+    long long* __restrict__ dbg) {
     constexpr int Hp = NHT * 32;
     constexpr int C4 = Hp / 4;               // float4 columns per weight row
     // DBG instantiation only (tools/stack_phase_timing.py): per-phase wall_clock64 stamps from workgroup 0.
@@ -50,8 +51,31 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     // dispatch) all row groups share ONE XCD's L2 and each weight line crosses the fabric once.  Pure
     // speed hint: results do not depend on where workgroups land.
     if (xcd_stride > 1 && (blockIdx.x % xcd_stride) != 0) return;
+    const int li = xcd_stride > 1 ? blockIdx.x / xcd_stride : blockIdx.x;      // logical workgroup index
+    if (li >= n_work) {
+        // L2 warm-up helper (same XCD as the workers under the observed block -> XCD dispatch): touch every
+        // weight line in pass order so the workers' loads hit this XCD's L2 (~110 GB/s per CU) instead of
+        // waiting on the fabric (~65 GB/s per CU).  Results cannot depend on it: the values are discarded.
+        const int hid = li - n_work, nh = (int)(gridDim.x / (xcd_stride > 1 ? xcd_stride : 1)) - n_work;
+        const int64_t n4 = (int64_t)(L - 1) * Hp * Hp / 4;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(Wh);
+        f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = (int64_t)hid * SF_THREADS + threadIdx.x; i < n4; i += (int64_t)nh * SF_THREADS) {
+            f32x4 v = w4[i];
+            sink[0] += v[0];
+        }
+        if (TRAIN && WhT != nullptr) {
+            const f32x4* t4 = reinterpret_cast<const f32x4*>(WhT);
+            for (int64_t i = n4 - 1 - ((int64_t)hid * SF_THREADS + threadIdx.x); i >= 0; i -= (int64_t)nh * SF_THREADS) {
+                f32x4 v = t4[i];                      // backward passes walk the layers from last to first
+                sink[1] += v[0];
+            }
+        }
+        asm volatile("" ::"v"(sink[0]), "v"(sink[1]));
+        return;
+    }
     const int t = threadIdx.x, c4 = t % C4, kq = t / C4;
-    const int r0 = (xcd_stride > 1 ? blockIdx.x / xcd_stride : blockIdx.x) * R;
+    const int r0 = li * R;
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
 
     // rows of this block: input of layer 2
@@ -431,6 +455,16 @@ static long long* g_sf_dbg = nullptr;
 extern "C" int loc_debug_set_buffer(void* p) { g_sf_dbg = (long long*)p; return 0; }
 static bool sf_probe_bwd_w() { static int v = -1; if (v < 0) { const char* e = getenv("LOC_DEBUG_BWD_USE_W"); v = e && atoi(e) ? 1 : 0; } return v == 1; }
 
+static int sf_helpers() {          // L2 warm-up helper workgroups (only meaningful with the XCD placement hint)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("LOC_STACK_HELPERS");
+        v = e ? atoi(e) : 12;         // measured: 0 -> 78.6 us, 4 -> 63, 8 -> 51.7, 12 -> 51.0, 32 -> 55 (width 256)
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+
 static int sf_xcd_stride() {
     static int v = -1;
     if (v < 0) {
@@ -447,18 +481,19 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
                                           const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
                                           float* head_out, void* stream) {
     const int xs = sf_xcd_stride();
+    const int nh = xs > 1 ? sf_helpers() : 0;
     if (sf_probe_bwd_w()) WhT = Wh;          // timing probe only: wrong numerics
 #define LAUNCH(N)                                                                                                  \
     if (g_sf_dbg)                                                                                                  \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, true>), dim3(32 / SF_R * xs), dim3(SF_THREADS), 0,   \
-                           (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre,   \
-                           n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs,         \
-                           g_sf_dbg);                                                                              \
+        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, true>), dim3((32 / SF_R + nh) * xs),                 \
+                           dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
+                           keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
+                           (float*)nullptr, xs, 32 / SF_R, g_sf_dbg);                                              \
     else                                                                                                           \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, false>), dim3(32 / SF_R * xs), dim3(SF_THREADS), 0,  \
-                           (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre,   \
-                           n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs,         \
-                           (long long*)nullptr);
+        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, false>), dim3((32 / SF_R + nh) * xs),                \
+                           dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
+                           keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
+                           (float*)nullptr, xs, 32 / SF_R, (long long*)nullptr);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -470,11 +505,12 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
                                       const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
     const int nblk = (n_b + SF_R - 1) / SF_R;
     const int xs = sf_xcd_stride();
+    const int nh = xs > 1 ? sf_helpers() : 0;
 #define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false, false>), dim3(nblk * xs), dim3(SF_THREADS), 0,                \
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
                        (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
-                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, (long long*)nullptr);
+                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, (long long*)nullptr);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
