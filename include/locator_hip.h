@@ -232,10 +232,19 @@ int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const 
  * bn_ready != 0: this step's [scale|shift|mean|rstd] is already in the workspace (loc_bn_epoch_stats or the
  * previous step's bn_next_stats) and the per-step statistics kernel is skipped.
  * bn_next_stats: [mean|var] of the next minibatch or NULL (see loc_l1_backward_adam).
+ * Consecutive steps must alternate the parity of t_off (they do: t_off = step index + 1): the per-step
+ * scratch is double-buffered on it.
  * ev_l1b0 / ev_l1b1: optional hipEvent_t recorded around the layer-1 backward kernel. */
 int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                   float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0, void* ev_l1b1,
-                   void* stream);
+                   float* loss_out, int bn_ready, const float* bn_next_stats, int wait_side, void* ev_l1b0,
+                   void* ev_l1b1, void* stream);
+/* With net->side_stream set, each step leaves its hidden-layer dW/Adam launch running on the side stream
+ * (it overlaps the next step's layer-1 forward).  wait_side != 0 makes a step wait for the previous step's
+ * side work before it reads the hidden weights (pass 0 only for the first step enqueued after a
+ * loc_train_join, e.g. the first step of a captured graph).  loc_train_join makes `stream` wait for the
+ * last step's side work: call it before loc_predict, before copying the weights, and at the end of a
+ * captured epoch. */
+int loc_train_join(const loc_net* net, void* stream);
 /* The workspace's bn4 block (where loc_bn_epoch_stats must leave step 0's values). */
 float* loc_workspace_bn4(const loc_net* net);
 /* Inference forward over n rows (any n >= 0) in blocks of 32: yhat[n][2]; dist[n] if with_targets. */

@@ -80,7 +80,8 @@ SIGNATURES = {
     "loc_stack_split_bytes": (C.c_int64, [C.c_int]),
     "loc_stack_forward_backward_split": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
                                                    C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
-    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
+    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
+    "loc_train_join": (C.c_int, [C.POINTER(Net), vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),
     "loc_event_destroy": (C.c_int, [vp]),

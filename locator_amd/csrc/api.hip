@@ -58,13 +58,17 @@ extern "C" int64_t loc_w1s_index(int h, int k, int Hp) { return w1s_index(h, k, 
 struct ws_view {
     float *bn4, *gbs, *partial, *acts, *adrop, *dz, *head_out;
 };
-static ws_view carve(const loc_dims* d, float* ws) {
+// The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity: with the
+// side-stream overlap the hidden-layer dW/Adam launch of step t still reads its activations while step
+// t+1's forward is already writing the next ones.
+static ws_view carve(const loc_dims* d, float* ws, int parity = 0) {
     ws_view v;
     const int64_t blk = 32 * (int64_t)d->Hp;
+    const int64_t per_step = (2 * (int64_t)d->L + 1) * blk + 256;
     v.bn4 = ws;
     v.gbs = v.bn4 + 4 * (int64_t)d->Kp;
     v.partial = v.gbs + 4 * (int64_t)d->Kp;
-    v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk;
+    v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk + (parity & 1) * per_step;
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
     v.head_out = v.dz + d->L * blk;
@@ -72,7 +76,7 @@ static ws_view carve(const loc_dims* d, float* ws) {
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
     const int64_t blk = 32 * (int64_t)d->Hp;
-    return 8 * (int64_t)d->Kp + ((int64_t)LOC_MAX_FWD_GRID + 2 * d->L + 1) * blk + 256;
+    return 8 * (int64_t)d->Kp + (int64_t)LOC_MAX_FWD_GRID * blk + 2 * ((2 * (int64_t)d->L + 1) * blk + 256);
 }
 
 #define TRY(x)                 \
@@ -83,9 +87,17 @@ extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
 
 extern "C" float* loc_workspace_bn4(const loc_net* net) { return carve(&net->d, net->ws).bn4; }
 
+extern "C" int loc_train_join(const loc_net* net, void* stream) {
+    if (net->side_stream && net->ev_join) {
+        hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)net->ev_join, 0);
+        if (e != hipSuccess) { loc_set_error("join side stream: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
+}
+
 extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                              float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
-                              void* ev_l1b1, void* stream) {
+                              float* loss_out, int bn_ready, const float* bn_next_stats, int wait_side,
+                              void* ev_l1b0, void* ev_l1b1, void* stream) {
     const loc_dims* d = &net->d;
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_train_step: n_b=%d out of 1..32", n_b); return -1; }
     const bool use_drop = net->drop_p > 0.f;
@@ -94,7 +106,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     loc_layout lay;
     loc_param_layout(d, &lay);
     float *P = net->params, *M = net->adam_m, *V = net->adam_v;
-    ws_view w = carve(d, net->ws);
+    ws_view w = carve(d, net->ws, t_off & 1);
     const int Hp = d->Hp, L = d->L, npre = d->n_pre;
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
     auto act = [&](int l) { return w.acts + (l - 1) * blk; };        // ELU output of layer l (1-based)
@@ -113,6 +125,10 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     }
     if (net->wht && loc_stack_fused_supported(Hp)) {
         // fused row-parallel hidden stack: 2 launches instead of 2(L-1)+2
+        const bool fork = net->side_stream && net->ev_fork && net->ev_join;
+        // the previous step's hidden-layer dW/Adam launch (side stream) must be done before the hidden
+        // weights are read again
+        if (fork && wait_side) TRY(loc_train_join(net, stream));
         if (net->gran && net->stack_err && loc_stack_split_enabled(Hp)) {
             TRY(loc_stack_forward_backward_split(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
                                                  P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre,
@@ -123,31 +139,28 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                                            P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b,
                                            rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
         }
-        // the hidden-layer dW/Adam launch only needs what the fused kernel left behind, the layer-1 backward
-        // only needs dz of layer 1: run them concurrently when a side stream is provided
-        const bool fork = net->side_stream && net->ev_fork && net->ev_join;
-        void* dw_stream = stream;
-        if (fork) {
-            hipError_t e = hipEventRecord((hipEvent_t)net->ev_fork, (hipStream_t)stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)net->side_stream, (hipEvent_t)net->ev_fork, 0);
-            if (e != hipSuccess) { loc_set_error("fork to side stream: %s", hipGetErrorString(e)); return (int)e; }
-            dw_stream = net->side_stream;
-        }
-        TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
-                              net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl, net->lr,
-                              net->t_base, t_off, dw_stream));
-        if (fork) {
-            hipError_t e = hipEventRecord((hipEvent_t)net->ev_join, (hipStream_t)net->side_stream);
-            if (e != hipSuccess) { loc_set_error("side stream record: %s", hipGetErrorString(e)); return (int)e; }
-        }
+        if (!fork)
+            TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+                                  net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
+                                  net->lr, net->t_base, t_off, stream));
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
         TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
                                  V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,
                                  V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
                                  net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, stream));
         if (fork) {
-            hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)net->ev_join, 0);
-            if (e != hipSuccess) { loc_set_error("join side stream: %s", hipGetErrorString(e)); return (int)e; }
+            // The hidden-layer dW/Adam launch needs only what the stack kernel left in this step's scratch
+            // parity, and nothing reads its results before the NEXT step's stack kernel.  Forked here, after
+            // the layer-1 backward (which saturates HBM and owns every CU), it overlaps the gamma/beta kernel
+            // and the next step's layer-1 forward + reduce instead of sitting on the critical path.
+            hipError_t e = hipEventRecord((hipEvent_t)net->ev_fork, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)net->side_stream, (hipEvent_t)net->ev_fork, 0);
+            if (e != hipSuccess) { loc_set_error("fork to side stream: %s", hipGetErrorString(e)); return (int)e; }
+            TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+                                  net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
+                                  net->lr, net->t_base, t_off, net->side_stream));
+            e = hipEventRecord((hipEvent_t)net->ev_join, (hipStream_t)net->side_stream);
+            if (e != hipSuccess) { loc_set_error("side stream record: %s", hipGetErrorString(e)); return (int)e; }
         }
         return 0;
     }

@@ -80,11 +80,12 @@ class LocatorNet:
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
         # side stream + fork/join events: hidden-layer dW/Adam overlaps the layer-1 backward
-        # (measured: the persistent layer-1 backward occupies every CU's register file, so the side launch
-        #  queues behind it and the join then costs more than the serial 10 us — off unless LOC_SIDE_STREAM=1)
+        # Opt-in (LOC_SIDE_STREAM=1).  Measured both ways: forked before the layer-1 backward (they fight for
+        # HBM and CUs) and forked after it / joined before the next stack kernel (144.9k vs 151.4k samples/s
+        # without): the cross-stream graph edges and contention with the forward cost more than the 10 us.
         import os
         self.side_stream = (torch.cuda.Stream(device=dev)
-                            if self.use_fused and os.environ.get("LOC_SIDE_STREAM") == "1" else None)
+                            if self.use_fused and os.environ.get("LOC_SIDE_STREAM", "0") == "1" else None)
         self._ev_fork, self._ev_join = C.c_void_p(), C.c_void_p()
         if self.side_stream is not None:
             _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_fork)), "event")
@@ -176,9 +177,11 @@ class LocatorNet:
         return out
 
     def export_params(self):
+        self.join_side()
         return self._export_flat(self.params)
 
     def export_adam(self):
+        self.join_side()
         return self._export_flat(self.adam_m, False), self._export_flat(self.adam_v, False)
 
     def _import_flat(self, flat, p, with_moving=True):
@@ -209,14 +212,21 @@ class LocatorNet:
         self.refresh_transposed()
 
     # ------------------------------------------------------------------ ops
-    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None):
+    def join_side(self):
+        """Make the current stream wait for the last step's side-stream work (hidden-layer dW/Adam)."""
+        if self.side_stream is not None:
+            net = self._net or self.cnet()
+            _lib.check(self.lib.loc_train_join(C.byref(net), _stream()), "loc_train_join")
+
+    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None,
+                   wait_side=True):
         """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
         mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view.
         bn_ready / bn_next: epoch-level BN statistics (see epoch_bn_stats)."""
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_train_step(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
-                                           _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next), ev0, ev1,
-                                           _stream()), "loc_train_step")
+                                           _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next),
+                                           1 if wait_side else 0, ev0, ev1, _stream()), "loc_train_step")
 
     def epoch_bn_stats(self, rows_all, batch, n_last, n_steps, stats_ep):
         """BN batch statistics of every minibatch of the epoch in one launch, the epoch's moving-statistics
@@ -231,6 +241,7 @@ class LocatorNet:
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
+        self.join_side()
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
                                         _ptr(dist), _stream()), "loc_predict")
@@ -242,6 +253,7 @@ class LocatorNet:
 
     def snapshot(self):
         """ModelCheckpoint(save_best_only, save_weights_only) as a device-side copy (locator.py:332-348)."""
+        self.join_side()
         if self.best is None:
             self.best = torch.empty_like(self.params)
         self.best.copy_(self.params)
