@@ -201,7 +201,7 @@ int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float*
                                const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
                                const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
                                float* head_out, void* stream);
-/* Inference counterpart: layers 2..L + heads for n_b <= 32 rows; yhat[n_b][2], optional dist[n_b]. */
+/* Inference counterpart: layers 2..L + heads for n_b rows (any n_b; a1 is [n_b][Hp]); yhat[n_b][2], optional dist[n_b]. */
 int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
                            const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
                            const float* Y, float* yhat, float* dist, void* stream);

@@ -208,17 +208,29 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,
                                  w.bn4, stream));
+    if (loc_stack_fused_supported(Hp)) {
+        // layer 1 per 32-row block into consecutive scratch slots (the L activation slots hold 32*L rows),
+        // then ONE row-parallel stack launch for the whole chunk
+        const int chunk = LOC_ROWS * L;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            const int nc = n - c0 < chunk ? n - c0 : chunk;
+            for (int i = 0; i < nc; i += LOC_ROWS) {
+                const int nb = nc - i < LOC_ROWS ? nc - i : LOC_ROWS;
+                TRY(loc_l1_forward(net->X, net->x_pitch, rows + c0 + i, nb, d, w.bn4, P + lay.w1, P + lay.b1,
+                                   w.partial, net->l1_fwd_grid, w.acts + (int64_t)(i / LOC_ROWS) * blk, nullptr,
+                                   nullptr, 1.f, stream));
+            }
+            TRY(loc_stack_forward_eval(w.acts, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
+                                       P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
+                                       with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,
+                                       with_targets ? dist + c0 : nullptr, stream));
+        }
+        return 0;
+    }
     for (int i = 0; i < n; i += LOC_ROWS) {
         const int nb = n - i < LOC_ROWS ? n - i : LOC_ROWS;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows + i, nb, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                            net->l1_fwd_grid, w.acts, nullptr, nullptr, 1.f, stream));
-        if (loc_stack_fused_supported(Hp)) {
-            TRY(loc_stack_forward_eval(w.acts, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
-                                       P + lay.bb, Hp, L, nb, with_targets ? rows + i : nullptr,
-                                       with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)i,
-                                       with_targets ? dist + i : nullptr, stream));
-            continue;
-        }
         for (int l = 2; l <= L; ++l)
             TRY(loc_dense_forward(w.acts + (l - 2) * blk, P + lay.wh + (l - 2) * HH,
                                   P + lay.bh + (int64_t)(l - 2) * Hp, Hp, w.acts + (l - 1) * blk, nullptr, nullptr,
