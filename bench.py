@@ -20,6 +20,8 @@ The JSON line also carries
                 after that kernel, vs 8 TB/s HBM; `traffic` = PMC-measured bytes (profiles/r01_pmc_traffic.json)
   cpu_baseline  the NumPy fp32 port of the same step (oracle/) timed on this box's host cores on a
                 bounded sample of the same workload.
+  l1_gemm       (N=1) the large-M first-layer genotype GEMM of the predict / validation sweeps over all rows,
+                as a fraction of the dense bf16-MFMA peak (outside the timed region; events on the stream).
 """
 import argparse
 import json
@@ -33,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (no sparsity)
 
 
 def l1_bwd_bytes(K, H, n_b):
@@ -45,6 +48,52 @@ def l1_bwd_bytes(K, H, n_b):
 def step_bytes(K, H, n_b, L=10):
     """SURVEY.md §8(d) bytes_step for a whole minibatch step."""
     return 28 * K * H + 2 * n_b * K + 64 * K + 28 * ((L - 1) * H * H + (L + 1) * H + 8)
+
+
+def l1_gemm_roofline(net, n_rows, iters=20):
+    """The only large-M contraction on the path (model.predict / validation, locator.py:414, :441):
+    a1 = ELU(BN(x) W1 + b1) for n_rows rows at once through loc_l1_forward_rows, timed with HIP events.
+    flops = 2*M*K*H counted ONCE, however many bf16 pieces carry each fp32 weight (3 = exact products)."""
+    import ctypes as C
+
+    import torch
+    from locator_amd import _lib
+    lib, d, lay = net.lib, net.d, net.lay
+    P = net.params.data_ptr()
+    dev = net.params.device
+    bn4 = torch.zeros(4 * d.Kp, device=dev)
+    _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
+                                            P + 4 * lay.mov_var, bn4.data_ptr(), None))
+    partial = torch.empty(256 * 128 * d.Hp, device=dev)
+    rows = torch.arange(n_rows, dtype=torch.int32, device=dev)
+    a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
+    out = {"rows": n_rows, "flops": 2.0 * n_rows * d.K * d.H, "bytes": float(n_rows * d.K + 4 * d.K * d.H),
+           "peak_tflops": BF16_PEAK_TFLOPS, "kernel": "l1_rows_partial_kernel + l1_reduce_kernel"}
+    for pieces in (3, 1):
+        if not lib.loc_l1_rows_supported(d.Hp, pieces):
+            continue
+
+        def run():
+            _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
+                                               C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
+                                               partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces, 0, None))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        tf = out["flops"] / us * 1e-6
+        out["bf16x%d" % pieces] = {"us": round(us, 1), "tflops": round(tf, 1),
+                                   "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
+                                   "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4),
+                                   "hbm_gbs": round(out["bytes"] / us * 1e-3, 1),
+                                   "exact_fp32_products": pieces == 3}
+    return out
 
 
 def cpu_baseline(x, y_norm, train, K, H, seconds=20.0):
@@ -226,6 +275,8 @@ def main():
             "final_loss": round(hist[-1][0], 5), "final_val_loss": round(hist[-1][1], 5),
             "roofline": roof,
         }
+        if world == 1:
+            out["l1_gemm"] = l1_gemm_roofline(net, n)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, np.nan_to_num(ynorm), train, K, H, args.cpu_seconds)
         else:

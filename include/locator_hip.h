@@ -41,6 +41,9 @@ extern "C" {
 #endif
 
 #define LOC_ROWS 32 /* rows per row-block = MFMA M; --batch_size <= 32 per launch */
+#define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
+#define LOC_PREDICT_CHUNK 1024 /* rows per large-M launch inside loc_predict                      */
+#define LOC_ROWS_BLOCKS 256    /* 128-row tiles the large-M scratch is sized for (one workgroup per CU)   */
 
 typedef struct loc_dims {
     int K;     /* SNPs after filtering                        (traingen.shape[1], locator.py:318) */
@@ -101,6 +104,9 @@ typedef struct loc_net {
     int* stack_err;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
+    int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
+                                products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
+                                32-row fp32-MFMA kernel for every block of rows                          */
 } loc_net;
 
 #define LOC_MAX_FWD_GRID 512
@@ -154,6 +160,18 @@ int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const float* bet
 int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                    const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
                    float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream);
+/* Large-M inference form of the same layer (model.predict / the validation pass of model.fit,
+ * locator.py:414, :441, :367-376): a1[m][h] for n rows (any n >= 1; a1 must hold ceil(n/128)*128 rows) on
+ * the bf16 matrix pipe.  Each fp32 weight (times the BatchNorm scale of its SNP) is split on chip into
+ * `pieces` bf16 values: 3 pieces reproduce it exactly, so with genotypes exact in bf16 every product is
+ * exact and the result equals the fp32 contraction up to summation order; 1 or 2 pieces are faster and
+ * approximate (2^-9 / 2^-17 relative per weight).  partial: scratch of partial_floats floats (at least
+ * ceil(n/128)*128*Hp; more scratch = more SNP groups = more workgroups, up to target_blocks, 0 = 256).
+ * loc_l1_rows_supported: whether the double-buffered bf16 tiles of this width fit the 160 KB LDS. */
+int loc_l1_rows_supported(int Hp, int pieces);
+int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
+                        const float* scale_shift, const float* w1s, const float* b1, float* partial,
+                        int64_t partial_floats, float* a1, int pieces, int target_blocks, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats
@@ -247,7 +265,9 @@ int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, 
 int loc_train_join(const loc_net* net, void* stream);
 /* The workspace's bn4 block (where loc_bn_epoch_stats must leave step 0's values). */
 float* loc_workspace_bn4(const loc_net* net);
-/* Inference forward over n rows (any n >= 0) in blocks of 32: yhat[n][2]; dist[n] if with_targets. */
+/* Inference forward over n rows (any n >= 0): yhat[n][2]; dist[n] if with_targets.  More than 32 rows go
+ * through loc_l1_forward_rows in chunks of LOC_PREDICT_CHUNK (net->predict_pieces), then one hidden-stack
+ * launch per chunk; up to 32 rows (or predict_pieces < 0) use the 32-row kernels. */
 int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets, float* dist,
                 void* stream);
 

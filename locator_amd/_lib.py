@@ -33,7 +33,8 @@ class Layout(C.Structure):
 class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
-                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("gran", vp), ("stack_err", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int)]
+                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("gran", vp), ("stack_err", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
+                ("predict_pieces", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -54,6 +55,9 @@ SIGNATURES = {
     "loc_bn_infer_scale_shift": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "loc_l1_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                  C.c_float, vp]),
+    "loc_l1_rows_supported": (C.c_int, [C.c_int, C.c_int]),
+    "loc_l1_forward_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int64, vp,
+                                      C.c_int, C.c_int, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
                                        vp, vp]),

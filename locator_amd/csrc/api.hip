@@ -56,8 +56,15 @@ extern "C" int loc_param_layout(const loc_dims* d, loc_layout* o) {
 extern "C" int64_t loc_w1s_index(int h, int k, int Hp) { return w1s_index(h, k, Hp / 32); }
 
 struct ws_view {
-    float *bn4, *gbs, *partial, *acts, *adrop, *dz, *head_out;
+    float *bn4, *gbs, *partial, *acts, *adrop, *dz, *head_out, *a1_rows;
+    int64_t partial_floats;
 };
+// scratch of the layer-1 forward partial sums: the 32-row kernel needs grid*32*Hp, the large-M kernel
+// LOC_ROWS_BLOCKS tiles of 128*Hp
+static int64_t partial_floats_of(const loc_dims* d) {
+    const int64_t a = (int64_t)LOC_MAX_FWD_GRID * 32 * d->Hp, b = (int64_t)LOC_ROWS_BLOCKS * LOC_ROWS_TILE * d->Hp;
+    return a > b ? a : b;
+}
 // The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity: with the
 // side-stream overlap the hidden-layer dW/Adam launch of step t still reads its activations while step
 // t+1's forward is already writing the next ones.
@@ -68,15 +75,18 @@ static ws_view carve(const loc_dims* d, float* ws, int parity = 0) {
     v.bn4 = ws;
     v.gbs = v.bn4 + 4 * (int64_t)d->Kp;
     v.partial = v.gbs + 4 * (int64_t)d->Kp;
-    v.acts = v.partial + (int64_t)LOC_MAX_FWD_GRID * blk + (parity & 1) * per_step;
+    v.partial_floats = partial_floats_of(d);
+    v.acts = v.partial + v.partial_floats + (parity & 1) * per_step;
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
     v.head_out = v.dz + d->L * blk;
+    v.a1_rows = v.partial + v.partial_floats + 2 * per_step;
     return v;
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
     const int64_t blk = 32 * (int64_t)d->Hp;
-    return 8 * (int64_t)d->Kp + (int64_t)LOC_MAX_FWD_GRID * blk + 2 * ((2 * (int64_t)d->L + 1) * blk + 256);
+    return 8 * (int64_t)d->Kp + partial_floats_of(d) + 2 * ((2 * (int64_t)d->L + 1) * blk + 256) +
+           (int64_t)LOC_PREDICT_CHUNK * d->Hp;
 }
 
 #define TRY(x)                 \
@@ -208,6 +218,20 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,
                                  w.bn4, stream));
+    const int pieces = net->predict_pieces == 0 ? 3 : net->predict_pieces;
+    if (n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) {
+        // large-M layer 1 on the bf16 matrix pipe, then ONE row-parallel stack launch per chunk
+        for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
+            const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
+            TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows + c0, nc, d, w.bn4, P + lay.w1, P + lay.b1,
+                                    w.partial, w.partial_floats, w.a1_rows, pieces, 0, stream));
+            TRY(loc_stack_forward_eval(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
+                                       P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
+                                       with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,
+                                       with_targets ? dist + c0 : nullptr, stream));
+        }
+        return 0;
+    }
     if (loc_stack_fused_supported(Hp)) {
         // layer 1 per 32-row block into consecutive scratch slots (the L activation slots hold 32*L rows),
         // then ONE row-parallel stack launch for the whole chunk

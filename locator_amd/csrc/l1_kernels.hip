@@ -265,14 +265,15 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
 
 // a1[b][h] = ELU(sum_g partial[g][b][h] + b1[h]); optional Dropout on this layer's output.
 // Block = 1024 threads = 64 consecutive outputs x 16 groups of partials; fixed summation order.
-__global__ __launch_bounds__(1024) void l1_reduce_kernel(const float* __restrict__ partial, int G, int Hp,
-                                                         const float* __restrict__ b1, float* __restrict__ a1,
+__global__ __launch_bounds__(1024) void l1_reduce_kernel(const float* __restrict__ partial, int G, int rows_p,
+                                                         int Hp, const float* __restrict__ b1,
+                                                         float* __restrict__ a1,
                                                          float* __restrict__ a1_drop,
                                                          const uint8_t* __restrict__ mask, float keep_scale) {
     __shared__ float red[16][64];
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o;
-    const int n = 32 * Hp;
+    const int n = rows_p * Hp;
     float bias = 0.f, keep = 1.f;
     if (q == 0) {
         bias = b1[idx % Hp];
@@ -568,7 +569,15 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
 #undef LAUNCH_FWD
     LOC_CHECK_LAUNCH();
     hipLaunchKernelGGL(l1_reduce_kernel, dim3(32 * d->Hp / 64), dim3(1024), 0, (hipStream_t)stream, partial, grid,
-                       d->Hp, b1, a1, a1_drop, mask, keep_scale);
+                       32, d->Hp, b1, a1, a1_drop, mask, keep_scale);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+// reduction of the large-M forward (l1_rows.hip): rows_p rows, no dropout
+int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const float* b1, float* a1, void* stream) {
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(rows_p * Hp / 64), dim3(1024), 0, (hipStream_t)stream, partial, G,
+                       rows_p, Hp, b1, a1, (float*)nullptr, (const uint8_t*)nullptr, 1.f);
     LOC_CHECK_LAUNCH();
     return 0;
 }

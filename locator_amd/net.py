@@ -79,6 +79,11 @@ class LocatorNet:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
+        # bf16 pieces per weight in the large-M inference forward (3 = exact fp32 products; see
+        # include/locator_hip.h loc_l1_forward_rows).  LOC_PREDICT_PIECES=1|2 trades accuracy for speed,
+        # -1 keeps every row block on the 32-row fp32-MFMA kernel.
+        import os
+        self.predict_pieces = int(os.environ.get("LOC_PREDICT_PIECES", "3"))
         # side stream + fork/join events: hidden-layer dW/Adam overlaps the layer-1 backward
         # Opt-in (LOC_SIDE_STREAM=1).  Measured both ways: forked before the layer-1 backward (they fight for
         # HBM and CUs) and forked after it / joined before the next stack kernel (144.9k vs 151.4k samples/s
@@ -114,6 +119,7 @@ class LocatorNet:
         if self.gran is not None:
             n.gran, n.stack_err = self.gran.data_ptr(), self.stack_err.data_ptr()
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
+        n.predict_pieces = self.predict_pieces
         self._net = n
         return n
 
@@ -152,7 +158,7 @@ class LocatorNet:
                                                      self.d.Hp, self.d.L - 1, _stream()), "loc_transpose_hidden")
 
     def _export_flat(self, flat, with_moving=True):
-        """Flat device buffer -> dict in the oracle's format (Keras orientation, un-padded)."""
+        """Flat device buffer -> dict of NumPy arrays in Keras orientation, un-padded (the format the tests compare against)."""
         d, lay, lib = self.d, self.lay, self.lib
         out = {}
         w1 = torch.empty((d.K, d.H), dtype=torch.float32, device=self.device)

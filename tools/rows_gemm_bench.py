@@ -1,0 +1,82 @@
+"""Times the large-M layer-1 forward (loc_l1_forward_rows) against the bf16-MFMA and HBM rooflines.
+
+    python tools/rows_gemm_bench.py [--snps 100000] [--width 256] [--rows 1000,450,90] [--iters 50]
+
+flops = 2*M*K*H (the contraction the reference's model.predict performs, counted once however many
+bf16 pieces carry each weight); bytes = M*K (uint8 genotypes) + 4*K*H (fp32 weights read once).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from locator_amd import _lib  # noqa: E402
+from locator_amd.net import LocatorNet  # noqa: E402
+
+BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--snps", type=int, default=100000)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--rows", default="1000,450,90")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--blocks", default="0")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    n_max = max(int(r) for r in a.rows.split(","))
+    g = torch.Generator(device="cpu").manual_seed(1)
+    X = (torch.rand((n_max, (a.snps + 31) // 32 * 32), generator=g) < 0.3).to(torch.uint8).to(dev)
+    Y = torch.zeros((n_max, 2), device=dev)
+    net = LocatorNet(X, Y, a.snps, a.width, 10, 0.25, seed=1)
+    lib, d, lay = net.lib, net.d, net.lay
+    P = net.params.data_ptr()
+    bn4 = torch.zeros(4 * d.Kp, device=dev)
+    _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
+                                            P + 4 * lay.mov_var, bn4.data_ptr(), None))
+    partial = torch.empty(512 * 128 * d.Hp, device=dev)
+    out = []
+    for n in [int(r) for r in a.rows.split(",")]:
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
+        for blocks in [int(b) for b in a.blocks.split(",")]:
+            for pieces in (3, 2, 1):
+                if not lib.loc_l1_rows_supported(d.Hp, pieces):
+                    continue
+
+                def run():
+                    _lib.check(lib.loc_l1_forward_rows(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
+                                                       bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
+                                                       partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces,
+                                                       blocks, None))
+                for _ in range(5):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / a.iters
+                flops = 2.0 * n * a.snps * a.width
+                byts = n * a.snps + 4.0 * a.snps * a.width
+                rec = {"rows": n, "snps": a.snps, "width": a.width, "pieces": pieces, "blocks": blocks,
+                       "us": round(us, 2),
+                       "tflops": round(flops / us * 1e-6, 1), "frac_bf16_peak": round(flops / us * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "mfma_issue_frac": round(pieces * flops / us * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "gbs": round(byts / us * 1e-3, 1), "frac_hbm_peak": round(byts / us * 1e-3 / HBM_PEAK_GBS, 4)}
+                print(json.dumps(rec), flush=True)
+                out.append(rec)
+    return out
+
+
+if __name__ == "__main__":
+    main()
