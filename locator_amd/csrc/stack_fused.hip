@@ -56,7 +56,11 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
         // L2 warm-up helper (same XCD as the workers under the observed block -> XCD dispatch): touch every
         // weight line in pass order so the workers' loads hit this XCD's L2 (~110 GB/s per CU) instead of
         // waiting on the fabric (~65 GB/s per CU).  Results cannot depend on it: the values are discarded.
-        const int hid = li - n_work, nh = (int)(gridDim.x / (xcd_stride > 1 ? xcd_stride : 1)) - n_work;
+        // with stride 8/n_x the logical workgroups cycle over n_x XCDs: the helpers that share this one's XCD
+        // (every n_x-th) split the weight lines between them, so each XCD's L2 sees all of them
+        const int n_x = xcd_stride > 1 ? 8 / xcd_stride : 1;
+        const int nh_all = (int)(gridDim.x / (xcd_stride > 1 ? xcd_stride : 1)) - n_work;
+        const int hid = (li - n_work) / n_x, nh = nh_all / n_x > 0 ? nh_all / n_x : 1;
         const int64_t n4 = (int64_t)(L - 1) * Hp * Hp / 4;
         const f32x4* w4 = reinterpret_cast<const f32x4*>(Wh);
         f32x4 sink = {0.f, 0.f, 0.f, 0.f};
@@ -504,8 +508,15 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
                                       const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
                                       const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
     const int nblk = (n_b + SF_R - 1) / SF_R;
-    const int xs = sf_xcd_stride();
-    const int nh = xs > 1 ? sf_helpers() : 0;
+    // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups
+    // than one XCD holds, spread them over 2, 4 or all 8 XCDs (stride 4, 2, 1) instead of running in rounds.
+    int xs = sf_xcd_stride();
+    int nh = xs > 1 ? sf_helpers() : 0;
+    while (xs > 1 && (nblk + nh + 8 / xs - 1) / (8 / xs) > 32) {
+        xs /= 2;
+        nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);      // the same number of helpers on every XCD in use
+    }
+    if (xs == 1) nh = 0;
 #define LAUNCH(N)                                                                                                 \
     hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
