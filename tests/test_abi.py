@@ -32,6 +32,25 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Layout) == 14 * 8
 
 
+def _struct_fields(src, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    return [re.search(r"([A-Za-z_0-9]+)\s*$", decl.strip()).group(1) for decl in body.split(";") if decl.strip()]
+
+
+def test_ctypes_structs_follow_the_header_field_for_field(repo_root):
+    """loc_net / loc_dims / loc_layout in include/locator_hip.h, the ctypes Structures in locator_amd/_lib.py
+    and the stub shown in INTEGRATION.md must list the same fields in the same order."""
+    src = open(os.path.join(repo_root, "include", "locator_hip.h")).read()
+    for cname, ctype in (("loc_dims", _lib.Dims), ("loc_layout", _lib.Layout), ("loc_net", _lib.Net)):
+        assert _struct_fields(src, cname) == [f[0] for f in ctype._fields_], cname
+    doc = open(os.path.join(repo_root, "INTEGRATION.md")).read()
+    stub = re.search(r"class Net\(C\.Structure\):\s*_fields_ = \[(.*?)\]\n", doc, flags=re.S).group(1)
+    assert re.findall(r'\("([a-z_0-9A-Z]+)"', stub) == [f[0] for f in _lib.Net._fields_]
+    # pointer / int64 / int / float members only: the natural-alignment size is what both compilers produce
+    assert C.sizeof(_lib.Net) % 8 == 0
+
+
 def test_dims_and_layout():
     d = _lib.make_dims(5830, 256, 10)
     assert (d.K, d.Kp, d.H, d.Hp, d.L, d.n_pre) == (5830, 5856, 256, 256, 10, 5)
