@@ -248,7 +248,8 @@ def main():
         try:    # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pm["workload"] == {"K": K, "H": H, "n": n}:
-                traffic = int(pm["kernels"]["l1_bwd_adam_kernel<%d>" % ((H + 31) // 32)]["traffic_bytes"])
+                key = [k for k in pm["kernels"] if k.startswith("l1_bwd_adam_kernel<%d" % ((H + 31) // 32))][0]
+                traffic = int(pm["kernels"][key]["traffic_bytes"])
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": "l1_bwd_adam_kernel", "achieved": round(achieved, 1),

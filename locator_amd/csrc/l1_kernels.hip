@@ -2,6 +2,8 @@
 // matrix + Dense(width, elu) (reference: /root/reference/locator/locator.py:318-320),
 // forward and fused backward+Adam.  All arithmetic fp32; contractions on
 // v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define KT 32  // SNPs per k-tile
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int f = t + 512 * i;
-            if (f < WF4) wreg[i] = src[f];
+            if (f < WF4) wreg[i] = src[f];   // default cache policy on purpose, see l1_bwd_adam_kernel
         }
         if (xvalid) {
             int k0 = kt * KT + 4 * xq;
@@ -307,7 +309,13 @@ __global__ __launch_bounds__(1024) void l1_reduce_kernel(const float* __restrict
 // the next unit's 12 KB into a second register set while it works on the current one:
 //     dW^T[h][k]  = sum_b dZ[b][h] xhat[b][k]      (A from LDS, B = xhat registers)
 //     dxhat[b][k] += sum_h dZ[b][h] W[h][k]        (A from LDS, B = the weight registers)
-// then Adam in registers and 16-byte stores.  There is no barrier and no cross-wave traffic in the
+// then Adam in registers and 16-byte stores.  Cache policy (template mask NTM: 1 = m,v loads, 8 = m,v
+// stores, 2 = W loads, 4 = W stores non-temporal): the Adam moments are touched exactly once per step, so
+// they stream non-temporally and stop evicting W1 (102 MB of the 256 MB Infinity Cache), which the next
+// forward and this kernel both re-read.  Measured (samples/s, 2 runs each): NTM 0 153.4k, 1 154.7k,
+// 8 156.1k, 9 157.9k, 13 (default) 158.0k; non-temporal W loads in the FORWARD cost 5-7 %
+// (backward 101 -> 110-114 us), so W loads keep the default policy everywhere.
+// There is no barrier and no cross-wave traffic in the
 // loop.  dxhat is only needed for BN's trainable gamma/beta (locator.py:318): each wave folds its
 // share into (sum_b dxhat*xn, sum_b dxhat) per SNP and leaves it in `gbs`; a k-tile is touched by at
 // most two waves (ranges are >= NHT units), slot 0 = the wave that did unit-tile 0, slot 1 = the
@@ -320,7 +328,7 @@ __device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, f
     w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
 }
 
-template <int NHT>
+template <int NHT, int NTM = 13>
 __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
@@ -398,9 +406,9 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         const f32x4* vp = reinterpret_cast<const f32x4*>(v1s + base);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            wq[q] = wp[q * 64 + lane];
-            mq[q] = mp[q * 64 + lane];
-            vq[q] = vp[q * 64 + lane];
+            wq[q] = (NTM & 2) ? __builtin_nontemporal_load(wp + q * 64 + lane) : wp[q * 64 + lane];
+            mq[q] = (NTM & 1) ? __builtin_nontemporal_load(mp + q * 64 + lane) : mp[q * 64 + lane];
+            vq[q] = (NTM & 1) ? __builtin_nontemporal_load(vp + q * 64 + lane) : vp[q * 64 + lane];
         }
     };
     auto step = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4], f32x4 (&wn)[4], f32x4 (&mn)[4],
@@ -443,9 +451,9 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
                 adam_update_fast(wv, mv, vv, g[q * 4 + c], alpha);
                 wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
             }
-            wp[q * 64 + lane] = wq[q];
-            mp[q * 64 + lane] = mq[q];
-            vp[q * 64 + lane] = vq[q];
+            if (NTM & 4) __builtin_nontemporal_store(wq[q], wp + q * 64 + lane); else wp[q * 64 + lane] = wq[q];
+            if (NTM & 8) __builtin_nontemporal_store(mq[q], mp + q * 64 + lane); else mp[q * 64 + lane] = mq[q];
+            if (NTM & 8) __builtin_nontemporal_store(vq[q], vp + q * 64 + lane); else vp[q * 64 + lane] = vq[q];
         }
     };
 
@@ -605,7 +613,25 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
     }
-    NHT_SWITCH(nht, LAUNCH_BWD)
+    // LOC_L1B_NT = 0 | 9 | 13 | 15 overrides the cache-policy mask NTM for width 256 (measurement knob)
+    static int ntm = -2;
+    if (ntm == -2) { const char* e = getenv("LOC_L1B_NT"); ntm = e ? atoi(e) : -1; }
+#define LAUNCH_BWD_NT(M)                                                                                       \
+    {                                                                                                          \
+        static size_t lds_set = 0;                                                                             \
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<8, M>, lds); if (rc) return rc; lds_set = lds; } \
+        hipLaunchKernelGGL((l1_bwd_adam_kernel<8, M>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
+                           rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
+    }
+    if (nht == 8 && ntm >= 0) {
+        switch (ntm) {
+            case 0: LAUNCH_BWD_NT(0) break; case 9: LAUNCH_BWD_NT(9) break; case 15: LAUNCH_BWD_NT(15) break;
+            default: LAUNCH_BWD_NT(13) break;
+        }
+    } else {
+        NHT_SWITCH(nht, LAUNCH_BWD)
+    }
 #undef LAUNCH_BWD
     LOC_CHECK_LAUNCH();
     if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);

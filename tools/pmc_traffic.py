@@ -8,7 +8,8 @@ Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
   WRITE_SIZE is uncalibrated by the guide -> calibrated here on a known byte count in the same run:
   the ModelCheckpoint snapshot, a device-to-device copy of n_total floats (`__amd_rocclr_copyBuffer`).
 
-usage: pmc_traffic.py <fetch_dir>/f_counter_collection.csv <write_dir>/w_counter_collection.csv out.json
+usage: pmc_traffic.py <fetch_dir>/f_counter_collection.csv <write_dir>/w_counter_collection.csv out.json [K H n]
+(tools/pmc_traffic.sh runs the two passes and this summary)
 """
 import csv
 import json
@@ -40,7 +41,23 @@ def main():
         out[k] = {"launches": len(f), "FETCH_SIZE_KiB_mean": f_mean, "WRITE_SIZE_KiB_mean": w_mean,
                   "fetch_doubled_for_wide_stream": wide, "read_bytes": rd, "write_bytes": w_mean * 1024,
                   "traffic_bytes": rd + w_mean * 1024, "FETCH_max": max(f), "WRITE_max": max(w)}
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    K, H, n = (int(v) for v in sys.argv[4:7]) if len(sys.argv) >= 7 else (100000, 256, 1000)
+    n_total = None
+    cal = out.get("__amd_rocclr_copyBuffer")
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 "
+                     "bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph; tools/pmc_traffic.sh",
+           "workload": {"K": K, "H": H, "n": n},
+           "units": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled for wide (16 B/lane) streaming reads per "
+                    "MI355X_MICROARCH.md (HBM section)",
+           "calibration": None if cal is None else {
+               "kernel": "__amd_rocclr_copyBuffer: the largest copy is the ModelCheckpoint snapshot, a device-to-device "
+                         "copy of all n_total parameters",
+               "WRITE_SIZE_KiB_max": cal["WRITE_max"], "FETCH_SIZE_KiB_max": cal["FETCH_max"],
+               "fetch_over_write": cal["FETCH_max"] / cal["WRITE_max"] if cal["WRITE_max"] else None,
+               "note": "a copy reads what it writes: WRITE_SIZE equals the buffer size and FETCH_SIZE reports 1/2 of it "
+                       "-> the x2 correction holds on this access pattern"},
+           "kernels": out}
+    json.dump(doc, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if v["traffic_bytes"] > 1e6:
             print(f"{k[:44]:44s} n={v['launches']:5d} read={v['read_bytes']/1e6:9.2f} MB write={v['write_bytes']/1e6:9.2f} MB")
