@@ -67,7 +67,7 @@ def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=p
     prepare       optional per-unit hook run in the worker before fit_fn (e.g. column resampling)
     fits_per_gpu  worker processes per GPU.  A single fit alternates between an HBM-bound phase (layer 1)
                   and a latency-bound phase (hidden stack, 16 CUs); two fits on one GPU interleave them:
-                  measured 170k vs 129k samples/s aggregate on the 1000 x 100k workload (1.32x), no further
+                  measured 209k vs 157k samples/s aggregate on the 1000 x 100k workload (1.33x), no further
                   gain from a third."""
     n_vis = visible_gpus()
     n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
