@@ -112,3 +112,40 @@ def test_unsupported_configurations_are_rejected_with_messages():
         LocatorNet(X, Y, 40, 64, 1)
     with pytest.raises(_lib.LocatorHipError, match="width"):
         LocatorNet(X, Y, 40, 600, 4)
+
+
+_KNOB_PROBE = r"""
+import hashlib, numpy as np, torch
+from tests.gpu_util import build_net, make_problem
+from locator_amd.train import EpochRunner
+x, y, p, rng = make_problem(70, 4096, 256, 4, seed=3)
+net = build_net(x, y, p, drop_p=0.25, seed=7)
+runner = EpochRunner(net, np.arange(60), np.arange(60, 70), 32, use_graph=False)
+out = []
+for e in range(2):
+    out.append(runner.run_epoch(np.random.default_rng(e).permutation(60)))
+torch.cuda.synchronize()
+print("DIGEST", hashlib.sha1(net.params.cpu().numpy().tobytes()).hexdigest(), repr(out))
+"""
+
+
+def _probe(env):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _KNOB_PROBE], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+
+
+def test_speed_knobs_do_not_change_a_single_bit():
+    """Cache policy of the layer-1 backward (LOC_L1B_NT), XCD placement / L2 warm-up helpers of the hidden
+    stack (LOC_STACK_XCD_STRIDE, LOC_STACK_HELPERS) are speed hints: two epochs of training (width 256, the
+    shape the knobs apply to) must leave bit-identical weights, losses and validation losses."""
+    ref = _probe({})
+    assert _probe({"LOC_L1B_NT": "0"}) == ref
+    assert _probe({"LOC_L1B_NT": "15"}) == ref
+    assert _probe({"LOC_STACK_XCD_STRIDE": "1", "LOC_STACK_HELPERS": "0"}) == ref
+    assert _probe({"LOC_STACK_HELPERS": "3"}) == ref
