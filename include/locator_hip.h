@@ -111,6 +111,17 @@ typedef struct loc_net {
 
 #define LOC_MAX_FWD_GRID 512
 
+/* BatchNorm gamma/beta update riding in the tail launch of a step (loc_stack_dw_adam_tail): the partial sums the
+ * layer-1 backward left in gbs, the six K-vectors, and optionally the next minibatch's batch statistics
+ * ([mean|var], from loc_bn_epoch_stats) from which the next step's [scale|shift|mean|rstd] goes to bn4. */
+typedef struct loc_gb_tail {
+    int K, Kp;
+    const float* gbs;
+    float *gamma, *beta, *m_gamma, *v_gamma, *m_beta, *v_beta;
+    const float* next_stats;
+    float* bn4;
+} loc_gb_tail;
+
 const char* loc_last_error(void);
 int loc_version(void);
 
@@ -185,6 +196,13 @@ int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows,
                          int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid,
                          const float* bn_next_stats, float* bn4_out, void* ev_after_main, void* stream);
 
+/* The main kernel of loc_l1_backward_adam alone (W1, b1 and the gamma/beta partial sums in gb_scratch); the
+ * caller runs the gamma/beta update itself -- loc_train_step folds it into loc_stack_dw_adam_tail. */
+int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                              const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s, float* b1,
+                              float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
+                              const float* lr, const int* t_base, int t_off, int grid, void* stream);
+
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,
                       const uint8_t* mask, float keep_scale, void* stream);
@@ -230,6 +248,14 @@ int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const flo
                       float* WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba, int64_t off_wb,
                       int64_t off_bb, float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
                       const int* t_base, int t_off, void* stream);
+/* The same launch with the step's other row-reducing tail riding along: extra workgroups apply the BatchNorm
+ * gamma/beta Adam update (gb non-NULL; see loc_gb_tail).  Must run after the layer-1 backward of the step. */
+int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts, const float* adrop,
+                           const float* dz, const float* head_out, float* params, float* adam_m, float* adam_v,
+                           float* WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
+                           int64_t off_wb, int64_t off_bb, float* loss_out, const float* alpha_tab,
+                           int alpha_tab_len, const float* lr, const int* t_base, int t_off, const loc_gb_tail* gb,
+                           void* stream);
 
 /* Experimental split-K form of loc_stack_forward_backward: 4 workgroups per row group exchange partial sums
  * through tagged 8-byte granules (agent-scope relaxed atomics; no placement assumption; bounded spins). */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "loc_l1_rows_supported": (C.c_int, [C.c_int, C.c_int]),
     "loc_l1_forward_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int64, vp,
                                       C.c_int, C.c_int, vp]),
+    "loc_l1_backward_adam_main": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
+                                            vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
                                        vp, vp]),
@@ -79,6 +81,9 @@ SIGNATURES = {
     "loc_stack_dw_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                     C.c_int, vp, vp, C.c_int, vp]),
+    "loc_stack_dw_adam_tail": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
+                                         C.c_int, vp, vp, C.c_int, vp, vp]),
     "loc_debug_set_buffer": (C.c_int, [vp]),
     "loc_stack_split_enabled": (C.c_int, [C.c_int]),
     "loc_stack_split_bytes": (C.c_int64, [C.c_int]),

@@ -149,10 +149,27 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                                            P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b,
                                            rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
         }
-        if (!fork)
-            TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
-                                  net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
-                                  net->lr, net->t_base, t_off, stream));
+        if (!fork) {
+            // stack -> layer-1 backward -> ONE tail launch for everything that reduces over the batch rows:
+            // hidden-layer dW/db + Adam, heads, batch loss, and the BatchNorm gamma/beta update (plus the next
+            // step's scale/shift).  The hidden tail only needs what the stack kernel left in scratch, so it can
+            // sit after the layer-1 backward and share a launch with the gamma/beta tail.
+            if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
+            TRY(loc_l1_backward_adam_main(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
+                                          V + lay.w1, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
+                                          net->t_base, t_off, net->l1_bwd_grid, stream));
+            if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+            loc_gb_tail gb;
+            gb.K = d->K; gb.Kp = d->Kp; gb.gbs = w.gbs;
+            gb.gamma = P + lay.gamma; gb.beta = P + lay.beta;
+            gb.m_gamma = M + lay.gamma; gb.v_gamma = V + lay.gamma;
+            gb.m_beta = M + lay.beta; gb.v_beta = V + lay.beta;
+            gb.next_stats = bn_next_stats; gb.bn4 = w.bn4;
+            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+                                       net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
+                                       net->lr, net->t_base, t_off, &gb, stream));
+            return 0;
+        }
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
         TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
                                  V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,

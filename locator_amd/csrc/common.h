@@ -40,6 +40,35 @@ __device__ __forceinline__ float adam_alpha(const float* alpha_tab, int alpha_ta
     return lr[0] * alpha_tab[t];
 }
 
+// gamma/beta Adam for SNP k from the per-wave partial sums left by l1_bwd_adam_kernel (fixed order: slot 0 +
+// slot 1), and -- if next_stats is given -- the NEXT minibatch's [scale|shift|mean|rstd] from its precomputed
+// batch statistics and the just-updated gamma/beta.  Shared by l1_gamma_beta_adam_kernel and the tail blocks of
+// stack_dw_all_kernel.
+__device__ __forceinline__ void gamma_beta_adam_body(int k, int Kp, const float* __restrict__ gbs,
+                                                     float* __restrict__ gamma, float* __restrict__ beta,
+                                                     float* __restrict__ m_gamma, float* __restrict__ v_gamma,
+                                                     float* __restrict__ m_beta, float* __restrict__ v_beta,
+                                                     float alpha, const float* __restrict__ next_stats,
+                                                     float* __restrict__ bn4) {
+    const float* g0 = gbs + (int64_t)(k >> 5) * 128 + (k & 31);
+    const float dg = g0[0] + g0[64], db = g0[32] + g0[96];
+    float wv = gamma[k], mv = m_gamma[k], vv = v_gamma[k];
+    adam_update(wv, mv, vv, dg, alpha);
+    const float g = wv;
+    gamma[k] = wv; m_gamma[k] = mv; v_gamma[k] = vv;
+    wv = beta[k]; mv = m_beta[k]; vv = v_beta[k];
+    adam_update(wv, mv, vv, db, alpha);
+    beta[k] = wv; m_beta[k] = mv; v_beta[k] = vv;
+    if (next_stats) {
+        const float mu = next_stats[k], rstd = 1.0f / sqrtf(next_stats[Kp + k] + BN_EPS);
+        const float sc = g * rstd;
+        bn4[k] = sc;
+        bn4[Kp + k] = wv - mu * sc;
+        bn4[2 * (int64_t)Kp + k] = mu;
+        bn4[3 * (int64_t)Kp + k] = rstd;
+    }
+}
+
 // ---- Philox4x32-10 counter RNG -------------------------------------------------
 struct philox4 {
     uint32_t v[4];

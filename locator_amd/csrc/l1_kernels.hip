@@ -479,22 +479,7 @@ __global__ void l1_gamma_beta_adam_kernel(int K, const float* __restrict__ gbs, 
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
-    const float* g0 = gbs + (int64_t)(k >> 5) * 128 + (k & 31);
-    const float dg = g0[0] + g0[64], db = g0[32] + g0[96];
-    float wv = gamma[k], mv = m_gamma[k], vv = v_gamma[k];
-    adam_update(wv, mv, vv, dg, alpha);
-    gamma[k] = wv; m_gamma[k] = mv; v_gamma[k] = vv;
-    wv = beta[k]; mv = m_beta[k]; vv = v_beta[k];
-    adam_update(wv, mv, vv, db, alpha);
-    beta[k] = wv; m_beta[k] = mv; v_beta[k] = vv;
-    if (next_stats) {   // the next minibatch's [scale|shift|mean|rstd] from its precomputed batch statistics
-        const float g = gamma[k], mu = next_stats[k], rstd = 1.0f / sqrtf(next_stats[Kp + k] + BN_EPS);
-        const float sc = g * rstd;
-        bn4[k] = sc;
-        bn4[Kp + k] = wv - mu * sc;
-        bn4[2 * (int64_t)Kp + k] = mu;
-        bn4[3 * (int64_t)Kp + k] = rstd;
-    }
+    gamma_beta_adam_body(k, Kp, gbs, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha, next_stats, bn4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,13 +575,12 @@ int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const 
     return 0;
 }
 
-extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
-                                    const loc_dims* d, const float* bn4, const float* dz1, float* w1s, float* m1s,
-                                    float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
-                                    float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
-                                    float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
-                                    const int* t_base, int t_off, int grid, const float* bn_next_stats,
-                                    float* bn4_out, void* ev_after_main, void* stream) {
+// main kernel only (W1 / b1); the gamma/beta update that consumes gb_scratch is launched by the caller
+extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                         const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
+                                         float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
+                                         float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
+                                         const float* lr, const int* t_base, int t_off, int grid, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..32", n_b); return -1; }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
@@ -634,6 +618,19 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
     }
 #undef LAUNCH_BWD
     LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                    const loc_dims* d, const float* bn4, const float* dz1, float* w1s, float* m1s,
+                                    float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
+                                    float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
+                                    float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
+                                    const int* t_base, int t_off, int grid, const float* bn_next_stats,
+                                    float* bn4_out, void* ev_after_main, void* stream) {
+    int rc = loc_l1_backward_adam_main(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, b1, m_b1, v_b1, gb_scratch,
+                                       alpha_tab, alpha_tab_len, lr, t_base, t_off, grid, stream);
+    if (rc) return rc;
     if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
                        gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,

@@ -304,8 +304,17 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
     const float* __restrict__ dz, const float* __restrict__ head_out, float* __restrict__ P, float* __restrict__ M,
     float* __restrict__ V, float* __restrict__ WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
     int64_t off_wb, int64_t off_bb, float* __restrict__ loss_out, const float* __restrict__ alpha_tab,
-    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off) {
+    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, loc_gb_tail gb) {
     constexpr int Hp = NHT * 32;
+    // Blocks past the tiles and the heads (only when gb.K > 0): BatchNorm gamma/beta Adam for 512 SNPs each,
+    // from the partial sums the layer-1 backward left -- the step's two row-reducing tails share one launch.
+    if ((int)blockIdx.x > (L - 1) * NHT * NHT) {
+        const int k = ((int)blockIdx.x - (L - 1) * NHT * NHT - 1) * 512 + (int)threadIdx.x;
+        if (k < gb.K)
+            gamma_beta_adam_body(k, gb.Kp, gb.gbs, gb.gamma, gb.beta, gb.m_gamma, gb.v_gamma, gb.m_beta, gb.v_beta,
+                                 adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off), gb.next_stats, gb.bn4);
+        return;
+    }
     __shared__ float gt[32][33];
     __shared__ float hsm[32][8];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
@@ -528,22 +537,35 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
     return 0;
 }
 
+extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts,
+                                      const float* adrop, const float* dz, const float* head_out, float* params,
+                                      float* adam_m, float* adam_v, float* WhT, int64_t off_wh, int64_t off_bh,
+                                      int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb,
+                                      float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
+                                      const int* t_base, int t_off, const loc_gb_tail* gb, void* stream) {
+    const int nht = Hp / 32;
+    loc_gb_tail g;
+    if (gb) g = *gb; else { g = loc_gb_tail{}; g.K = 0; }
+    const int grid = (L - 1) * nht * nht + 1 + (g.K > 0 ? (g.K + 511) / 512 : 0);
+#define LAUNCH(N)                                                                                                 \
+    hipLaunchKernelGGL(stack_dw_all_kernel<N>, dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b,      \
+                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
+                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off, g);
+    SF_SWITCH(LAUNCH)
+#undef LAUNCH
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts,
                                  const float* adrop, const float* dz, const float* head_out, float* params,
                                  float* adam_m, float* adam_v, float* WhT, int64_t off_wh, int64_t off_bh,
                                  int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb, float* loss_out,
                                  const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                  int t_off, void* stream) {
-    const int nht = Hp / 32;
-    const int grid = (L - 1) * nht * nht + 1;
-#define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL(stack_dw_all_kernel<N>, dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b,      \
-                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
-                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off);
-    SF_SWITCH(LAUNCH)
-#undef LAUNCH
-    LOC_CHECK_LAUNCH();
-    return 0;
+    return loc_stack_dw_adam_tail(Hp, L, n_pre, n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT,
+                                  off_wh, off_bh, off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len,
+                                  lr, t_base, t_off, nullptr, stream);
 }
 
 // =============================================================================================
