@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--snps", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32, help="--batch_size of the fit (headline: 32, the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
@@ -181,7 +182,7 @@ def main():
         X = gather_columns(X, so, K)
     Y = torch.from_numpy(np.nan_to_num(ynorm).astype(np.float32)).to(dev)
     net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=rank, device=dev)
-    runner = EpochRunner(net, train, test, 32, use_graph=not args.no_graph)
+    runner = EpochRunner(net, train, test, args.batch, use_graph=not args.no_graph)
     cb = Callbacks(100, 1e-3)
     rng = np.random.default_rng(99 + rank)
     n_train, steps_per_epoch = runner.n_train, runner.steps
@@ -267,7 +268,7 @@ def main():
             "warmup": max(args.warmup, 2), "ms_per_step": round(ms_epoch, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {n} ind x {K} SNPs uint8 (BASELINE.json configs[2]), single model "
-                                   f"fit per GPU, batch 32, {n_train} train / {len(test)} validation",
+                                   f"fit per GPU, batch {args.batch}, {n_train} train / {len(test)} validation",
                        "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + callbacks",
                        "width": H, "nlayers": 10, "graph": not args.no_graph,
                        "replicates": "1 model per GPU, bootstrap resample per rank" if world > 1 else "single model"},

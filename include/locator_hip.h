@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define LOC_ROWS 32 /* rows per row-block = MFMA M; --batch_size <= 32 per launch */
+#define LOC_ROWS 32 /* rows per row block = MFMA M                                              */
+#define LOC_MAX_BATCH 64 /* --batch_size limit: two row blocks per step                          */
+#define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
 #define LOC_PREDICT_CHUNK 1024 /* rows per large-M launch inside loc_predict                      */
 #define LOC_ROWS_BLOCKS 256    /* 128-row tiles the large-M scratch is sized for (one workgroup per CU)   */
@@ -104,6 +106,8 @@ typedef struct loc_net {
     int* stack_err;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
+    int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32), or
+                                LOC_BATCH_SLOT when --batch_size is 33..LOC_MAX_BATCH                    */
     int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
                                 32-row fp32-MFMA kernel for every block of rows                          */
@@ -235,8 +239,8 @@ int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_hidden, void
 int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
                                const float* wa, const float* ba, const float* wb, const float* bb,
                                const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
-                               const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
-                               float* head_out, void* stream);
+                               int slot_rows, const int32_t* rows, const float* Y, float* acts, float* adrop,
+                               float* dz, float* head_out, void* stream);
 /* Inference counterpart: layers 2..L + heads for n_b rows (any n_b; a1 is [n_b][Hp]); yhat[n_b][2], optional dist[n_b]. */
 int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
                            const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
@@ -250,7 +254,7 @@ int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const flo
                       const int* t_base, int t_off, void* stream);
 /* The same launch with the step's other row-reducing tail riding along: extra workgroups apply the BatchNorm
  * gamma/beta Adam update (gb non-NULL; see loc_gb_tail).  Must run after the layer-1 backward of the step. */
-int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts, const float* adrop,
+int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int use_drop, const float* acts, const float* adrop,
                            const float* dz, const float* head_out, float* params, float* adam_m, float* adam_v,
                            float* WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
                            int64_t off_wb, int64_t off_bb, float* loss_out, const float* alpha_tab,

@@ -34,7 +34,7 @@ class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
                 ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("gran", vp), ("stack_err", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
-                ("predict_pieces", C.c_int)]
+                ("slot_rows", C.c_int), ("predict_pieces", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -76,12 +76,12 @@ SIGNATURES = {
     "loc_stack_fused_supported": (C.c_int, [C.c_int]),
     "loc_transpose_hidden": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "loc_stack_forward_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int,
-                                             C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+                                             C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "loc_stack_forward_eval": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "loc_stack_dw_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                     C.c_int, vp, vp, C.c_int, vp]),
-    "loc_stack_dw_adam_tail": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+    "loc_stack_dw_adam_tail": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                          C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                          C.c_int, vp, vp, C.c_int, vp, vp]),
     "loc_debug_set_buffer": (C.c_int, [vp]),

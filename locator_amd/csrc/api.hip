@@ -67,11 +67,16 @@ static int64_t partial_floats_of(const loc_dims* d) {
 }
 // The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity: with the
 // side-stream overlap the hidden-layer dW/Adam launch of step t still reads its activations while step
-// t+1's forward is already writing the next ones.
-static ws_view carve(const loc_dims* d, float* ws, int parity = 0) {
+// t+1's forward is already writing the next ones.  One activation slot holds `slot` rows (32, or
+// LOC_BATCH_SLOT when --batch_size > 32); the workspace is always sized for the larger one.
+static int slot_of(const loc_net* net) { return net->slot_rows > LOC_ROWS ? LOC_BATCH_SLOT : LOC_ROWS; }
+static int64_t per_step_floats(const loc_dims* d, int slot) {
+    return (2 * (int64_t)d->L + 1) * slot * d->Hp + 8 * (int64_t)slot;
+}
+static ws_view carve(const loc_dims* d, float* ws, int parity = 0, int slot = LOC_ROWS) {
     ws_view v;
-    const int64_t blk = 32 * (int64_t)d->Hp;
-    const int64_t per_step = (2 * (int64_t)d->L + 1) * blk + 256;
+    const int64_t blk = (int64_t)slot * d->Hp;
+    const int64_t per_step = per_step_floats(d, slot);
     v.bn4 = ws;
     v.gbs = v.bn4 + 4 * (int64_t)d->Kp;
     v.partial = v.gbs + 4 * (int64_t)d->Kp;
@@ -80,12 +85,11 @@ static ws_view carve(const loc_dims* d, float* ws, int parity = 0) {
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
     v.head_out = v.dz + d->L * blk;
-    v.a1_rows = v.partial + v.partial_floats + 2 * per_step;
+    v.a1_rows = v.partial + v.partial_floats + 2 * per_step_floats(d, LOC_BATCH_SLOT);
     return v;
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
-    const int64_t blk = 32 * (int64_t)d->Hp;
-    return 8 * (int64_t)d->Kp + partial_floats_of(d) + 2 * ((2 * (int64_t)d->L + 1) * blk + 256) +
+    return 8 * (int64_t)d->Kp + partial_floats_of(d) + 2 * per_step_floats(d, LOC_BATCH_SLOT) +
            (int64_t)LOC_PREDICT_CHUNK * d->Hp;
 }
 
@@ -109,31 +113,52 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                               float* loss_out, int bn_ready, const float* bn_next_stats, int wait_side,
                               void* ev_l1b0, void* ev_l1b1, void* stream) {
     const loc_dims* d = &net->d;
-    if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_train_step: n_b=%d out of 1..32", n_b); return -1; }
+    const int slot = slot_of(net);
+    const int max_b = slot > LOC_ROWS ? LOC_MAX_BATCH : LOC_ROWS;
+    if (n_b < 1 || n_b > max_b) { loc_set_error("loc_train_step: n_b=%d out of 1..%d", n_b, max_b); return -1; }
     const bool use_drop = net->drop_p > 0.f;
     if (use_drop && !mask) { loc_set_error("loc_train_step: dropout_prop > 0 needs a keep mask"); return -1; }
     const float ks = use_drop ? 1.0f / (1.0f - net->drop_p) : 1.0f;
     loc_layout lay;
     loc_param_layout(d, &lay);
     float *P = net->params, *M = net->adam_m, *V = net->adam_v;
-    ws_view w = carve(d, net->ws, t_off & 1);
+    ws_view w = carve(d, net->ws, t_off & 1, slot);
     const int Hp = d->Hp, L = d->L, npre = d->n_pre;
-    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    const int64_t blk = (int64_t)slot * Hp, HH = (int64_t)Hp * Hp;
     auto act = [&](int l) { return w.acts + (l - 1) * blk; };        // ELU output of layer l (1-based)
     auto dzl = [&](int l) { return w.dz + (l - 1) * blk; };          // dLoss/dz of layer l
     auto in_of = [&](int l) { return (use_drop && l - 1 == npre) ? w.adrop : act(l - 1); };  // input of layer l >= 2
     const float* at = net->alpha_tab;
     const int atl = net->alpha_tab_len;
 
+    const bool fused = net->wht && loc_stack_fused_supported(Hp);
+    if (slot > LOC_ROWS) {
+        // --batch_size > 32: the step is linear in the rows (BatchNorm is the first layer, so its batch statistics
+        // depend on the data only), hence the same kernels with two 32-row blocks per weight tile
+        if (!fused || (use_drop && npre == 1) || !loc_l1_rows_supported(Hp, 3) || net->side_stream ||
+            (net->gran && loc_stack_split_enabled(Hp))) {
+            loc_set_error("loc_train_step: --batch_size > 32 needs width 64/128/256 (after padding), nlayers >= 4 "
+                          "when dropout is on, and none of the experimental stream / split-K modes");
+            return -1;
+        }
+        if (!bn_ready && n_b > LOC_ROWS) {
+            loc_set_error("loc_train_step: more than 32 rows need the epoch-level BN statistics (loc_bn_epoch_stats)");
+            return -1;
+        }
+    }
     if (!bn_ready)
         TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
                                P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
-    {
+    if (n_b > LOC_ROWS) {
+        // large-M forward, exact fp32 products (3 bf16 pieces); fills one whole 128-row activation slot
+        TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
+                                w.partial_floats, act(1), 3, 0, stream));
+    } else {
         const bool dr = use_drop && npre == 1;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                            net->l1_fwd_grid, act(1), dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
     }
-    if (net->wht && loc_stack_fused_supported(Hp)) {
+    if (fused) {
         // fused row-parallel hidden stack: 2 launches instead of 2(L-1)+2
         const bool fork = net->side_stream && net->ev_fork && net->ev_join;
         // the previous step's hidden-layer dW/Adam launch (side stream) must be done before the hidden
@@ -147,7 +172,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         } else {
             TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
                                            P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b,
-                                           rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
+                                           slot, rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
         }
         if (!fork) {
             // stack -> layer-1 backward -> ONE tail launch for everything that reduces over the batch rows:
@@ -165,7 +190,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
             gb.m_gamma = M + lay.gamma; gb.v_gamma = V + lay.gamma;
             gb.m_beta = M + lay.beta; gb.v_beta = V + lay.beta;
             gb.next_stats = bn_next_stats; gb.bn4 = w.bn4;
-            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
                                        net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
                                        net->lr, net->t_base, t_off, &gb, stream));
             return 0;

@@ -328,7 +328,12 @@ __device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, f
     w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
 }
 
-template <int NHT, int NTM = 13>
+// RB = row blocks of 32 the kernel is built for (--batch_size <= 32*RB); RB = 1 is the default path.  With
+// RB > 1 every weight tile takes the gradient of all row blocks before its single Adam update (the step is
+// linear in the rows: BatchNorm is the first layer, its batch statistics depend on the data only), at
+// unchanged weight traffic.  To stay inside the register file the RB > 1 build keeps the genotypes of a
+// k-tile as packed bytes and re-derives xhat / xn when an MFMA needs them.
+template <int NHT, int NTM = 13, int RB = 1>
 __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
@@ -338,16 +343,17 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     constexpr int Hp = NHT * 32;
     constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dzl = smem;                                        // [32][PZ]
-    int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);      // [32]
+    float* dzl = smem;                                             // [32*RB][PZ]
+    int* rows_l = reinterpret_cast<int*>(dzl + 32 * RB * PZ);      // [32*RB]
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
     const int nkt = Kp / KT;
+    const int nrb = RB == 1 ? 1 : (n_b + 31) / 32;                 // row blocks in use (wave-uniform)
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
 
-    for (int i = t; i < 32 * Hp; i += 256) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
-    if (t < 32) rows_l[t] = t < n_b ? rows[t] : 0;
+    for (int i = t; i < 32 * nrb * Hp; i += 256) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
+    if (t < 32 * RB) rows_l[t] = t < n_b ? rows[t] : 0;
     __syncthreads();
 
     // bias of layer 1: db1[h] = sum_b dZ[b][h]   (block 0 only)
@@ -355,7 +361,12 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         for (int ht = w; ht < NHT; ht += 4) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ht * 32 + jl];
+            for (int rb = 0; rb < RB; ++rb) {
+                if (rb < nrb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += dzl[(32 * rb + rowmap(r, hi)) * PZ + ht * 32 + jl];
+                }
+            }
             s += __shfl_xor(s, 32);
             if (hi == 0) {
                 int h = ht * 32 + jl;
@@ -376,16 +387,43 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const float* mu_p = bn4 + 2 * (int64_t)Kp;
     const float* rs_p = bn4 + 3 * (int64_t)Kp;
 
-    float xh[16], xn[16];
-    f32x16 dx = {0};
+    // genotypes of the current k-tile for this lane's SNP: rows rowmap(r, hi) + 32*rb.
+    // RB == 1: xhat / xn kept as floats (as tuned); RB > 1: packed bytes + the four BN scalars.
+    float xh[RB == 1 ? 16 : 1], xn[RB == 1 ? 16 : 1];
+    uint32_t xb[RB == 1 ? 1 : RB][4];
+    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f;
+    auto xhat = [&](int rb, int r) -> float {
+        if constexpr (RB == 1) return xh[r];
+        else {
+            const bool ok = 32 * rb + rowmap(r, hi) < n_b;
+            const float xv = (float)((xb[rb][r >> 2] >> (8 * (r & 3))) & 255u);
+            return ok ? fmaf(xv, k_sc, k_sh) : 0.f;
+        }
+    };
+    auto xnorm = [&](int rb, int r) -> float {
+        if constexpr (RB == 1) return xn[r];
+        else {
+            const bool ok = 32 * rb + rowmap(r, hi) < n_b;
+            const float xv = (float)((xb[rb][r >> 2] >> (8 * (r & 3))) & 255u);
+            return ok ? (xv - k_mu) * k_rs : 0.f;
+        }
+    };
+    f32x16 dx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) dx[rb] = f32x16{0};
     int cur_kt = -1, first_ht = 0;
 
     auto flush = [&](int kt, int last_ht) {
         float pg = 0.f, pb = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            pg = fmaf(dx[r], xn[r], pg);
-            pb += dx[r];
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb < nrb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pg = fmaf(dx[rb][r], xnorm(rb, r), pg);
+                    pb += dx[rb][r];
+                }
+            }
         }
         pg += __shfl_xor(pg, 32);
         pb += __shfl_xor(pb, 32);
@@ -418,27 +456,57 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
             if (cur_kt >= 0) flush(cur_kt, NHT - 1);
             const int k = kt * KT + jl;
             const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k], rs = rs_p[k];
+            if constexpr (RB == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int b = rowmap(r, hi);
-                float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
-                bool ok = b < n_b;
-                xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
-                xn[r] = ok ? (xv - mu) * rs : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    int b = rowmap(r, hi);
+                    float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
+                    bool ok = b < n_b;
+                    xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
+                    xn[r] = ok ? (xv - mu) * rs : 0.f;
+                }
+            } else {
+                k_sc = sc; k_sh = sh; k_mu = mu; k_rs = rs;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xb[rb][q] = 0u;
+                    if (rb < nrb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t xv = X[(int64_t)rows_l[32 * rb + rowmap(r, hi)] * pitch + k];
+                            xb[rb][r >> 2] |= xv << (8 * (r & 3));
+                        }
+                    }
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[rb][r] = 0.f;
             cur_kt = kt;
             first_ht = ht;
         }
         if (u + 1 < u1) load_unit(u + 1, wn, mn, vn);
-        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
+        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = 32*rb + rowmap(s, hi)
         f32x16 g = {0};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ht * 32 + jl], xh[s], g);
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb < nrb) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    g = mfma32(dzl[(32 * rb + rowmap(s, hi)) * PZ + ht * 32 + jl], xhat(rb, s), g);
+            }
+        }
         // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dx = mfma32(dzl[jl * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb < nrb) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    dx[rb] = mfma32(dzl[(32 * rb + jl) * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx[rb]);
+            }
+        }
         const int64_t base = (int64_t)u * 1024;
         f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
         f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
@@ -521,7 +589,7 @@ extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32
 extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last,
                                   int n_steps, int K, int Kp, const float* gamma, const float* beta,
                                   float* mov_mean, float* mov_var, float* stats_ep, float* bn4, void* stream) {
-    if (batch < 1 || batch > LOC_ROWS || n_last < 1 || n_last > batch || n_steps < 1) {
+    if (batch < 1 || batch > LOC_MAX_BATCH || n_last < 1 || n_last > batch || n_steps < 1) {
         loc_set_error("loc_bn_epoch_stats: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
         return -1;
     }
@@ -581,14 +649,39 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
                                          float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
                                          float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
                                          const float* lr, const int* t_base, int t_off, int grid, void* stream) {
-    if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..32", n_b); return -1; }
+    if (n_b < 1 || n_b > LOC_MAX_BATCH) {
+        loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..%d", n_b, LOC_MAX_BATCH);
+        return -1;
+    }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
     // one contiguous range of >= NHT units per active wave, so a k-tile is split over at most two waves
     int n_active = grid * 4;
     if (n_active > nkt) n_active = nkt;
     grid = (n_active + 3) / 4;
-    const size_t lds = ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float);
+    const int rb = n_b > LOC_ROWS ? 2 : 1;
+    const size_t lds = ((size_t)32 * rb * (d->Hp + 1) + 32 * rb) * sizeof(float);
+    if (rb == 2) {
+        // more than 32 rows: two row blocks per weight tile (widths of the fused hidden stack only)
+#define LAUNCH_BWD2(N)                                                                                         \
+    {                                                                                                          \
+        static size_t lds_set = 0;                                                                             \
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N, 13, 2>, lds); if (rc) return rc; lds_set = lds; } \
+        hipLaunchKernelGGL((l1_bwd_adam_kernel<N, 13, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
+                           rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
+    }
+        switch (nht) {
+            case 2: LAUNCH_BWD2(2) break;
+            case 4: LAUNCH_BWD2(4) break;
+            case 8: LAUNCH_BWD2(8) break;
+            case 16: LAUNCH_BWD2(16) break;
+            default: loc_set_error("loc_l1_backward_adam: more than 32 rows need width 64/128/256/512 after padding (got %d)", d->Hp); return -1;
+        }
+#undef LAUNCH_BWD2
+        LOC_CHECK_LAUNCH();
+        return 0;
+    }
 #define LAUNCH_BWD(N)                                                                                          \
     {                                                                                                          \
         static size_t lds_set = 0;                                                                             \

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
     float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work,
-    long long* __restrict__ dbg) {
+    long long* __restrict__ dbg, int slot_rows) {
     constexpr int Hp = NHT * 32;
     constexpr int C4 = Hp / 4;               // float4 columns per weight row
     // DBG instantiation only (tools/stack_phase_timing.py): per-phase wall_clock64 stamps from workgroup 0.
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     }
     const int t = threadIdx.x, c4 = t % C4, kq = t / C4;
     const int r0 = li * R;
-    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;      // slot = activations of one layer
 
     // rows of this block: input of layer 2
     for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = a1_in[(int64_t)(r0 + i / Hp) * Hp + i % Hp];
@@ -298,13 +298,14 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
 //   Adam by all 512 threads, and the transposed copy W_l^T refreshed through LDS.  Tile row 0 also does db.
 // Last block: heads (dWa, dba, dWb, dbb + Adam) and the batch loss.
 // ---------------------------------------------------------------------------------------------
-template <int NHT>
+template <int NHT, int RB>
 __global__ __launch_bounds__(512) void stack_dw_all_kernel(
     int L, int n_pre, int n_b, int use_drop, const float* __restrict__ acts, const float* __restrict__ adrop,
     const float* __restrict__ dz, const float* __restrict__ head_out, float* __restrict__ P, float* __restrict__ M,
     float* __restrict__ V, float* __restrict__ WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
     int64_t off_wb, int64_t off_bb, float* __restrict__ loss_out, const float* __restrict__ alpha_tab,
-    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, loc_gb_tail gb) {
+    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, loc_gb_tail gb,
+    int slot_rows) {
     constexpr int Hp = NHT * 32;
     // Blocks past the tiles and the heads (only when gb.K > 0): BatchNorm gamma/beta Adam for 512 SNPs each,
     // from the partial sums the layer-1 backward left -- the step's two row-reducing tails share one launch.
@@ -316,9 +317,10 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         return;
     }
     __shared__ float gt[32][33];
-    __shared__ float hsm[32][8];
+    __shared__ float hsm[32 * RB][8];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
-    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
+    const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;
+    constexpr int nrb = RB;                            // 32-row blocks in use (1 unless --batch_size > 32)
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
     const int n_tiles = (L - 1) * NHT * NHT;
 
@@ -342,22 +344,25 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
             wv[i] = W2[idx[i]]; mv[i] = mW2[idx[i]]; vv[i] = vW2[idx[i]];
         }
         if (w == 0) {
-            float av[16], bv[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int b = 2 * s + hi;
-                av[s] = in2[b * Hp + kt * 32 + jl];
-                bv[s] = dz2[b * Hp + nt * 32 + jl];
-            }
             f32x16 g = {0};
+            float sb = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
+            for (int rb = 0; rb < nrb; ++rb) {
+                float av[16], bv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int b = 32 * rb + 2 * s + hi;
+                    av[s] = in2[b * Hp + kt * 32 + jl];
+                    bv[s] = dz2[b * Hp + nt * 32 + jl];
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sb += bv[i];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) gt[rowmap(r, hi)][jl] = g[r];
             if (kt == 0) {
-                float sb = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sb += bv[i];
                 sb += __shfl_xor(sb, 32);
                 if (hi == 0) {
                     const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + jl;
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         return;
     }
     // ---- head block
-    if (t < 256) hsm[t >> 3][t & 7] = head_out[t];
+    constexpr int nrow = 32 * nrb;
+    for (int i = t; i < 8 * nrow; i += 512) hsm[i >> 3][i & 7] = head_out[i];
     __syncthreads();
     const float* aL = acts + (int64_t)(L - 1) * blk;
     if (t == 0) {
@@ -402,13 +408,13 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         int64_t off;
         if (q < 4) {            // dWb[i][j] = sum_b y1[b][i] dy2[b][j]
             const int i = q >> 1, j = q & 1;
-            for (int b = 0; b < 32; ++b) g += hsm[b][3 + i] * hsm[b][5 + j];
+            for (int b = 0; b < nrow; ++b) g += hsm[b][3 + i] * hsm[b][5 + j];
             off = off_wb + q;
         } else if (q < 6) {     // dbb[j] = sum_b dy2[b][j]
-            for (int b = 0; b < 32; ++b) g += hsm[b][5 + (q - 4)];
+            for (int b = 0; b < nrow; ++b) g += hsm[b][5 + (q - 4)];
             off = off_bb + (q - 4);
         } else {                // dba[c] = sum_b dy1[b][c]
-            for (int b = 0; b < 32; ++b) g += hsm[b][1 + (q - 6)];
+            for (int b = 0; b < nrow; ++b) g += hsm[b][1 + (q - 6)];
             off = off_ba + (q - 6);
         }
         float wv = P[off], mv = M[off], vv = V[off];
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
     for (int k = t; k < Hp; k += 512) {      // dWa[k][c] = sum_b a_L[b][k] dy1[b][c]
         float g0 = 0.f, g1 = 0.f;
 #pragma unroll 8
-        for (int b = 0; b < 32; ++b) {
+        for (int b = 0; b < nrow; ++b) {
             const float av = aL[b * Hp + k];
             g0 = fmaf(av, hsm[b][1], g0);
             g1 = fmaf(av, hsm[b][2], g1);
@@ -491,22 +497,34 @@ static int sf_xcd_stride() {
 extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
                                           const float* wa, const float* ba, const float* wb, const float* bb,
                                           const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
-                                          const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
-                                          float* head_out, void* stream) {
-    const int xs = sf_xcd_stride();
-    const int nh = xs > 1 ? sf_helpers() : 0;
+                                          int slot_rows, const int32_t* rows, const float* Y, float* acts,
+                                          float* adrop, float* dz, float* head_out, void* stream) {
+    if (n_b < 1 || n_b > slot_rows || slot_rows % 32) {
+        loc_set_error("loc_stack_forward_backward: n_b=%d, slot_rows=%d", n_b, slot_rows);
+        return -1;
+    }
+    // every row of the row blocks in use is carried (rows >= n_b get a zero loss gradient), so the tail and the
+    // layer-1 backward can contract whole 32-row blocks
+    const int nblk = (n_b + 31) / 32 * (32 / SF_R);
+    int xs = sf_xcd_stride();
+    int nh = xs > 1 ? sf_helpers() : 0;
+    while (xs > 1 && (nblk + nh + 8 / xs - 1) / (8 / xs) > 32) {     // more row groups than one XCD holds
+        xs /= 2;
+        nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);
+    }
+    if (xs == 1) nh = 0;
     if (sf_probe_bwd_w()) WhT = Wh;          // timing probe only: wrong numerics
 #define LAUNCH(N)                                                                                                  \
     if (g_sf_dbg)                                                                                                  \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, true>), dim3((32 / SF_R + nh) * xs),                 \
+        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, true>), dim3((nblk + nh) * xs),                      \
                            dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
                            keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
-                           (float*)nullptr, xs, 32 / SF_R, g_sf_dbg);                                              \
+                           (float*)nullptr, xs, nblk, g_sf_dbg, slot_rows);                                        \
     else                                                                                                           \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, false>), dim3((32 / SF_R + nh) * xs),                \
+        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, false>), dim3((nblk + nh) * xs),                     \
                            dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
                            keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
-                           (float*)nullptr, xs, 32 / SF_R, (long long*)nullptr);
+                           (float*)nullptr, xs, nblk, (long long*)nullptr, slot_rows);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -530,27 +548,38 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
     hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
                        (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
-                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, (long long*)nullptr);
+                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, (long long*)nullptr, 32);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts,
+extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int use_drop, const float* acts,
                                       const float* adrop, const float* dz, const float* head_out, float* params,
                                       float* adam_m, float* adam_v, float* WhT, int64_t off_wh, int64_t off_bh,
                                       int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb,
                                       float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
                                       const int* t_base, int t_off, const loc_gb_tail* gb, void* stream) {
+    if (n_b < 1 || n_b > LOC_MAX_BATCH || n_b > slot_rows) {
+        loc_set_error("loc_stack_dw_adam: n_b=%d (limit %d), slot_rows=%d", n_b, LOC_MAX_BATCH, slot_rows);
+        return -1;
+    }
     const int nht = Hp / 32;
     loc_gb_tail g;
     if (gb) g = *gb; else { g = loc_gb_tail{}; g.K = 0; }
     const int grid = (L - 1) * nht * nht + 1 + (g.K > 0 ? (g.K + 511) / 512 : 0);
 #define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL(stack_dw_all_kernel<N>, dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b,      \
-                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
-                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off, g);
+    if (n_b > 32)                                                                                                 \
+        hipLaunchKernelGGL((stack_dw_all_kernel<N, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre,  \
+                           n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh,  \
+                           off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off,  \
+                           g, slot_rows);                                                                         \
+    else                                                                                                          \
+        hipLaunchKernelGGL((stack_dw_all_kernel<N, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre,  \
+                           n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh,  \
+                           off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off,  \
+                           g, slot_rows);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -563,7 +592,7 @@ extern "C" int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop
                                  int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb, float* loss_out,
                                  const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                  int t_off, void* stream) {
-    return loc_stack_dw_adam_tail(Hp, L, n_pre, n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT,
+    return loc_stack_dw_adam_tail(Hp, L, n_pre, n_b, 32, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT,
                                   off_wh, off_bh, off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len,
                                   lr, t_base, t_off, nullptr, stream);
 }

@@ -16,6 +16,8 @@ from . import _lib
 ALPHA_TAB_LEN = 32769            # beyond this t the Adam bias correction is 1 to fp32 precision
 ADAM_B1, ADAM_B2 = 0.9, 0.999
 LOC_ROWS = 32
+LOC_MAX_BATCH = 64       # include/locator_hip.h: two 32-row blocks per step
+LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
 
 
@@ -84,6 +86,7 @@ class LocatorNet:
         # -1 keeps every row block on the 32-row fp32-MFMA kernel.
         import os
         self.predict_pieces = int(os.environ.get("LOC_PREDICT_PIECES", "3"))
+        self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
         # side stream + fork/join events: hidden-layer dW/Adam overlaps the layer-1 backward
         # Opt-in (LOC_SIDE_STREAM=1).  Measured both ways: forked before the layer-1 backward (they fight for
         # HBM and CUs) and forked after it / joined before the next stack kernel (144.9k vs 151.4k samples/s
@@ -103,6 +106,23 @@ class LocatorNet:
         self._net = None
         self.init_weights()
 
+    def set_batch(self, batch_size):
+        """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..64 rows run two
+        row blocks per weight tile (same weight traffic per step) on a 128-row activation scratch."""
+        if not 1 <= batch_size <= LOC_MAX_BATCH:
+            raise ValueError(f"--batch_size must be in 1..{LOC_MAX_BATCH} for the HIP path (got {batch_size})")
+        if batch_size > LOC_ROWS:
+            if not self.use_fused or self.d.Hp > 256:
+                raise ValueError("--batch_size > 32 needs a --width that pads to 64, 128 or 256 "
+                                 "(33..64, 97..128 or 225..256)")
+            if self.drop_p > 0 and self.d.n_pre < 2:
+                raise ValueError("--batch_size > 32 with dropout needs --nlayers >= 4")
+            if self.side_stream is not None or self.gran is not None:
+                raise ValueError("--batch_size > 32 is not available with LOC_SIDE_STREAM / LOC_STACK_SPLIT")
+        self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
+        self._net = None
+        return self.slot_rows
+
     # ------------------------------------------------------------------ C struct
     def cnet(self):
         n = _lib.Net()
@@ -119,6 +139,7 @@ class LocatorNet:
         if self.gran is not None:
             n.gran, n.stack_err = self.gran.data_ptr(), self.stack_err.data_ptr()
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
+        n.slot_rows = self.slot_rows
         n.predict_pieces = self.predict_pieces
         self._net = n
         return n

@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-from .net import LOC_ROWS, LocatorNet
+from .net import LocatorNet
 
 
 class Callbacks:
@@ -64,8 +64,7 @@ class EpochRunner:
     """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
 
     def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True):
-        if not 1 <= batch_size <= LOC_ROWS:
-            raise ValueError(f"--batch_size must be in 1..{LOC_ROWS} for the HIP path (got {batch_size})")
+        self.slot_rows = net.set_batch(int(batch_size))      # validates 1..64 and the shape constraints
         self.net = net
         dev = net.device
         self.batch = int(batch_size)
@@ -77,7 +76,7 @@ class EpochRunner:
         self.perm_host = torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory()
         self.perm_dev = torch.zeros(self.steps * self.batch, dtype=torch.int32, device=dev)
         Hp = net.d.Hp
-        self.mask_stride = LOC_ROWS * Hp
+        self.mask_stride = self.slot_rows * Hp
         self.masks = (torch.zeros(self.steps * self.mask_stride, dtype=torch.uint8, device=dev)
                       if net.drop_p > 0 else None)
         self.stats = torch.zeros(self.steps + max(self.n_val, 1), dtype=torch.float32, device=dev)

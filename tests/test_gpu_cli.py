@@ -108,3 +108,21 @@ def test_jacknife_keep_weights_and_matrix_input(tmp_path):
     full = pd.read_csv(f"{out}_bootFULL_predlocs.txt")
     jk = pd.read_csv(f"{out}_boot0_predlocs.txt")
     assert not np.allclose(full["x"], jk["x"])          # 5 % of SNPs redrawn
+
+
+def test_batch_size_64_and_rejected_batch_sizes(tmp_path, capsys):
+    """--batch_size above the reference default: 64 rows per step (7 steps per epoch on the 405 training
+    samples, last batch of 21) trains to the same neighbourhood; 65 is rejected with the limit in the message."""
+    out = str(tmp_path / "b64")
+    _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", out, "--seed", "12345", "--max_epochs", "200",
+          "--patience", "30", "--keras_verbose", "0", "--batch_size", "64"])
+    h = pd.read_csv(out + "_history.txt", sep="\t")
+    assert 30 <= len(h) <= 200 and h["loss"].iloc[-1] < 0.5 * h["loss"].iloc[0]
+    assert json.load(open(out + "_params.json"))["batch_size"] == 64
+    txt = capsys.readouterr().out
+    r2x = float(txt.split("R2(x)=")[1].split("\n")[0])
+    err = float(txt.split("mean validation error ")[1].split("\n")[0])
+    assert r2x > 0.85 and err < 8.0, (r2x, err)
+    with pytest.raises(ValueError, match=r"1\.\.64"):
+        _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", str(tmp_path / "b65"), "--seed", "1",
+              "--max_epochs", "2", "--keras_verbose", "0", "--batch_size", "65"])

@@ -1,6 +1,7 @@
 """Edge cases on the GPU path: shapes the reference tolerates (or crashes on) that the HIP path must
 handle or reject loudly — odd layer counts, widths that are not multiples of 32, fewer SNPs than a
-tile, training sets smaller than a batch, batch sizes below 32, no samples to predict."""
+tile, training sets smaller than a batch, batch sizes below 32 and between 33 and 64, no samples to
+predict."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +18,10 @@ pytestmark = pytest.mark.gpu
     (300, 64, 4, 7, 30),       # --batch_size 7: five steps per epoch, last batch of 2
     (64, 256, 3, 32, 12),      # training set smaller than one batch
     (257, 33, 5, 16, 33),      # width 33 -> 64, K = 8 tiles + 1 SNP, last batch of 1
+    (300, 64, 4, 64, 150),     # --batch_size 64: two row blocks per step, last batch of 22 (one block)
+    (5830, 256, 10, 48, 200),  # --batch_size 48 on the fixture's shape: second row block half full, last batch of 8
+    (1000, 128, 6, 33, 100),   # --batch_size 33: one row spills into the second block; last batch of 1
+    (700, 100, 5, 64, 64),     # exactly one full 64-row step per epoch; width 100 -> 128
 ])
 def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     """3 epochs of fit (eager epoch 0, captured graph afterwards) vs oracle.fit with the same init,
@@ -31,7 +36,7 @@ def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     masks, hist = [], {"loss": [], "val_loss": []}
     for e in range(3):
         l, vl = runner.run_epoch(perms[e])
-        masks.append(runner.masks.cpu().numpy().reshape(runner.steps, 32, net.d.Hp).copy())
+        masks.append(runner.masks.cpu().numpy().reshape(runner.steps, runner.slot_rows, net.d.Hp).copy())
         hist["loss"].append(l)
         hist["val_loss"].append(vl)
     pref = O.copy_params(p)
@@ -112,6 +117,20 @@ def test_unsupported_configurations_are_rejected_with_messages():
         LocatorNet(X, Y, 40, 64, 1)
     with pytest.raises(_lib.LocatorHipError, match="width"):
         LocatorNet(X, Y, 40, 600, 4)
+    # --batch_size: 1..64; above 32 only on the fused-stack widths up to 256 and with Dropout after layer >= 2
+    from locator_amd.train import EpochRunner
+    tr, va = np.arange(6), np.arange(6, 8)
+    with pytest.raises(ValueError, match="batch_size"):
+        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 65)
+    with pytest.raises(ValueError, match="batch_size"):
+        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 0)
+    with pytest.raises(ValueError, match="width"):
+        EpochRunner(LocatorNet(X, Y, 40, 512, 4), tr, va, 64)
+    with pytest.raises(ValueError, match="width"):
+        EpochRunner(LocatorNet(X, Y, 40, 32, 4), tr, va, 40)
+    with pytest.raises(ValueError, match="nlayers"):
+        EpochRunner(LocatorNet(X, Y, 40, 64, 3, 0.25), tr, va, 40)
+    EpochRunner(LocatorNet(X, Y, 40, 64, 3, 0.0), tr, va, 40)          # no dropout: any depth >= 2 is fine
 
 
 _KNOB_PROBE = r"""
