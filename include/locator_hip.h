@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define LOC_ROWS 32 /* rows per row block = MFMA M                                              */
-#define LOC_MAX_BATCH 64 /* --batch_size limit: two row blocks per step                          */
+#define LOC_MAX_BATCH 128 /* --batch_size limit: four 32-row blocks per step                        */
 #define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
 #define LOC_PREDICT_CHUNK 1024 /* rows per large-M launch inside loc_predict                      */

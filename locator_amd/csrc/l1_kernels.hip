@@ -4,6 +4,8 @@
 // v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define KT 32  // SNPs per k-tile
@@ -328,13 +330,25 @@ __device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, f
     w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), so that register arrays
+// indexed by the row block never degrade to scratch memory when the unroller gives up
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 // RB = row blocks of 32 the kernel is built for (--batch_size <= 32*RB); RB = 1 is the default path.  With
 // RB > 1 every weight tile takes the gradient of all row blocks before its single Adam update (the step is
 // linear in the rows: BatchNorm is the first layer, its batch statistics depend on the data only), at
 // unchanged weight traffic.  To stay inside the register file the RB > 1 build keeps the genotypes of a
 // k-tile as packed bytes and re-derives xhat / xn when an MFMA needs them.
+// Workgroup: 4 waves, two workgroups per CU (RB <= 2); with RB >= 3 the dz image leaves room for one
+// workgroup per CU only, so it carries all 8 waves (the stream needs ~190 KB in flight per CU).
 template <int NHT, int NTM = 13, int RB = 1>
-__global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
+__global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_adam_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
     float* __restrict__ v1s, float* __restrict__ gbs, float* __restrict__ b1, float* __restrict__ m_b1,
@@ -342,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
     constexpr int Hp = NHT * 32;
     constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
+    constexpr int NT = RB > 2 ? 512 : 256, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                                             // [32*RB][PZ]
     int* rows_l = reinterpret_cast<int*>(dzl + 32 * RB * PZ);      // [32*RB]
@@ -352,21 +367,21 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const int nrb = RB == 1 ? 1 : (n_b + 31) / 32;                 // row blocks in use (wave-uniform)
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
 
-    for (int i = t; i < 32 * nrb * Hp; i += 256) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
+    for (int i = t; i < 32 * nrb * Hp; i += NT) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
     if (t < 32 * RB) rows_l[t] = t < n_b ? rows[t] : 0;
     __syncthreads();
 
     // bias of layer 1: db1[h] = sum_b dZ[b][h]   (block 0 only)
     if (blockIdx.x == 0) {
-        for (int ht = w; ht < NHT; ht += 4) {
+        for (int ht = w; ht < NHT; ht += NW) {
             float s = 0.f;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
+            static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
+                constexpr int rb = decltype(RBI)::value;
                 if (rb < nrb) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s += dzl[(32 * rb + rowmap(r, hi)) * PZ + ht * 32 + jl];
                 }
-            }
+            });
             s += __shfl_xor(s, 32);
             if (hi == 0) {
                 int h = ht * 32 + jl;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         }
     }
 
-    const int gw = blockIdx.x * 4 + w;
+    const int gw = blockIdx.x * NW + w;
     if (gw >= n_active) return;
     const int64_t U = (int64_t)nkt * NHT;
     const int u0 = (int)((int64_t)gw * U / n_active), u1 = (int)((int64_t)(gw + 1) * U / n_active);
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     float xh[RB == 1 ? 16 : 1], xn[RB == 1 ? 16 : 1];
     uint32_t xb[RB == 1 ? 1 : RB][4];
     float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f;
-    auto xhat = [&](int rb, int r) -> float {
+    auto xhat = [&](int rb, int r) __attribute__((always_inline)) -> float {
         if constexpr (RB == 1) return xh[r];
         else {
             const bool ok = 32 * rb + rowmap(r, hi) < n_b;
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
             return ok ? fmaf(xv, k_sc, k_sh) : 0.f;
         }
     };
-    auto xnorm = [&](int rb, int r) -> float {
+    auto xnorm = [&](int rb, int r) __attribute__((always_inline)) -> float {
         if constexpr (RB == 1) return xn[r];
         else {
             const bool ok = 32 * rb + rowmap(r, hi) < n_b;
@@ -409,14 +424,13 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         }
     };
     f32x16 dx[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) dx[rb] = f32x16{0};
+    static_for<RB>([&](auto RBI) __attribute__((always_inline)) { dx[decltype(RBI)::value] = f32x16{0}; });
     int cur_kt = -1, first_ht = 0;
 
-    auto flush = [&](int kt, int last_ht) {
+    auto flush = [&](int kt, int last_ht) __attribute__((always_inline)) {
         float pg = 0.f, pb = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
+            constexpr int rb = decltype(RBI)::value;
             if (rb < nrb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
                     pb += dx[rb][r];
                 }
             }
-        }
+        });
         pg += __shfl_xor(pg, 32);
         pb += __shfl_xor(pb, 32);
         if (hi == 0) {
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
             }
         }
     };
-    auto load_unit = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
+    auto load_unit = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) __attribute__((always_inline)) {
         const int64_t base = (int64_t)u * 1024;
         const f32x4* wp = reinterpret_cast<const f32x4*>(w1s + base);
         const f32x4* mp = reinterpret_cast<const f32x4*>(m1s + base);
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         }
     };
     auto step = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4], f32x4 (&wn)[4], f32x4 (&mn)[4],
-                    f32x4 (&vn)[4]) {
+                    f32x4 (&vn)[4]) __attribute__((always_inline)) {
         const int kt = u / NHT, ht = u - kt * NHT;
         if (kt != cur_kt) {   // wave-uniform
             if (cur_kt >= 0) flush(cur_kt, NHT - 1);
@@ -467,8 +481,8 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
                 }
             } else {
                 k_sc = sc; k_sh = sh; k_mu = mu; k_rs = rs;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
+                static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
+                    constexpr int rb = decltype(RBI)::value;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xb[rb][q] = 0u;
                     if (rb < nrb) {
@@ -478,35 +492,32 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
                             xb[rb][r >> 2] |= xv << (8 * (r & 3));
                         }
                     }
-                }
+                });
             }
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dx[rb][r] = 0.f;
+            static_for<RB>([&](auto RBI) __attribute__((always_inline)) { dx[decltype(RBI)::value] = f32x16{0}; });
             cur_kt = kt;
             first_ht = ht;
         }
         if (u + 1 < u1) load_unit(u + 1, wn, mn, vn);
         // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = 32*rb + rowmap(s, hi)
         f32x16 g = {0};
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
+            constexpr int rb = decltype(RBI)::value;
             if (rb < nrb) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     g = mfma32(dzl[(32 * rb + rowmap(s, hi)) * PZ + ht * 32 + jl], xhat(rb, s), g);
             }
-        }
+        });
         // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
+            constexpr int rb = decltype(RBI)::value;
             if (rb < nrb) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     dx[rb] = mfma32(dzl[(32 * rb + jl) * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx[rb]);
             }
-        }
+        });
         const int64_t base = (int64_t)u * 1024;
         f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
         f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
@@ -659,26 +670,34 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     int n_active = grid * 4;
     if (n_active > nkt) n_active = nkt;
     grid = (n_active + 3) / 4;
-    const int rb = n_b > LOC_ROWS ? 2 : 1;
+    const int rb = (n_b + LOC_ROWS - 1) / LOC_ROWS;
     const size_t lds = ((size_t)32 * rb * (d->Hp + 1) + 32 * rb) * sizeof(float);
-    if (rb == 2) {
-        // more than 32 rows: two row blocks per weight tile (widths of the fused hidden stack only)
-#define LAUNCH_BWD2(N)                                                                                         \
+    if (rb > 1) {
+        // more than 32 rows: RB row blocks per weight tile (widths of the fused hidden stack up to 256 only).
+        // RB = 2 keeps two workgroups per CU (66 KB of dz each at width 256); RB = 3, 4 run one per CU.
+#define LAUNCH_BWD_RB(N, R)                                                                                    \
     {                                                                                                          \
         static size_t lds_set = 0;                                                                             \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N, 13, 2>, lds); if (rc) return rc; lds_set = lds; } \
-        hipLaunchKernelGGL((l1_bwd_adam_kernel<N, 13, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N, 13, R>, lds); if (rc) return rc; lds_set = lds; } \
+        hipLaunchKernelGGL((l1_bwd_adam_kernel<N, 13, R>), dim3(R > 2 ? (n_active + 7) / 8 : grid),              \
+                           dim3(R > 2 ? 512 : 256), lds, (hipStream_t)stream, X, x_pitch,                      \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
     }
+#define LAUNCH_BWD_N(N)                                                                                        \
+    switch (rb) {                                                                                              \
+        case 2: LAUNCH_BWD_RB(N, 2) break;                                                                     \
+        case 3: LAUNCH_BWD_RB(N, 3) break;                                                                     \
+        default: LAUNCH_BWD_RB(N, 4) break;                                                                    \
+    }
         switch (nht) {
-            case 2: LAUNCH_BWD2(2) break;
-            case 4: LAUNCH_BWD2(4) break;
-            case 8: LAUNCH_BWD2(8) break;
-            case 16: LAUNCH_BWD2(16) break;
-            default: loc_set_error("loc_l1_backward_adam: more than 32 rows need width 64/128/256/512 after padding (got %d)", d->Hp); return -1;
+            case 2: LAUNCH_BWD_N(2) break;
+            case 4: LAUNCH_BWD_N(4) break;
+            case 8: LAUNCH_BWD_N(8) break;
+            default: loc_set_error("loc_l1_backward_adam: more than 32 rows need width 64/128/256 after padding (got %d)", d->Hp); return -1;
         }
-#undef LAUNCH_BWD2
+#undef LAUNCH_BWD_N
+#undef LAUNCH_BWD_RB
         LOC_CHECK_LAUNCH();
         return 0;
     }

@@ -569,19 +569,20 @@ extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slo
     loc_gb_tail g;
     if (gb) g = *gb; else { g = loc_gb_tail{}; g.K = 0; }
     const int grid = (L - 1) * nht * nht + 1 + (g.K > 0 ? (g.K + 511) / 512 : 0);
+#define LAUNCH_RB(N, R)                                                                                           \
+    hipLaunchKernelGGL((stack_dw_all_kernel<N, R>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b, \
+                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
+                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off, g, slot_rows);
 #define LAUNCH(N)                                                                                                 \
-    if (n_b > 32)                                                                                                 \
-        hipLaunchKernelGGL((stack_dw_all_kernel<N, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre,  \
-                           n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh,  \
-                           off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off,  \
-                           g, slot_rows);                                                                         \
-    else                                                                                                          \
-        hipLaunchKernelGGL((stack_dw_all_kernel<N, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre,  \
-                           n_b, use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh,  \
-                           off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off,  \
-                           g, slot_rows);
+    switch ((n_b + 31) / 32) {                                                                                    \
+        case 1: LAUNCH_RB(N, 1) break;                                                                            \
+        case 2: LAUNCH_RB(N, 2) break;                                                                            \
+        case 3: LAUNCH_RB(N, 3) break;                                                                            \
+        default: LAUNCH_RB(N, 4) break;                                                                           \
+    }
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH_RB
     LOC_CHECK_LAUNCH();
     return 0;
 }

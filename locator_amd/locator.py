@@ -16,7 +16,7 @@ Deliberate, documented deviations:
     (same content);
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
-  * --batch_size is limited to 64 rows (the reference default is 32) and --nlayers must be >= 2;
+  * --batch_size is limited to 128 rows (the reference default is 32) and --nlayers must be >= 2;
   * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed (recorded at the end of params.json).
 """
 from __future__ import annotations

@@ -16,7 +16,7 @@ from . import _lib
 ALPHA_TAB_LEN = 32769            # beyond this t the Adam bias correction is 1 to fp32 precision
 ADAM_B1, ADAM_B2 = 0.9, 0.999
 LOC_ROWS = 32
-LOC_MAX_BATCH = 64       # include/locator_hip.h: two 32-row blocks per step
+LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
 
@@ -107,8 +107,8 @@ class LocatorNet:
         self.init_weights()
 
     def set_batch(self, batch_size):
-        """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..64 rows run two
-        row blocks per weight tile (same weight traffic per step) on a 128-row activation scratch."""
+        """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..128 rows run two to
+        four row blocks per weight tile (same weight traffic per step) on a 128-row activation scratch."""
         if not 1 <= batch_size <= LOC_MAX_BATCH:
             raise ValueError(f"--batch_size must be in 1..{LOC_MAX_BATCH} for the HIP path (got {batch_size})")
         if batch_size > LOC_ROWS:

@@ -1,6 +1,6 @@
 """Edge cases on the GPU path: shapes the reference tolerates (or crashes on) that the HIP path must
 handle or reject loudly — odd layer counts, widths that are not multiples of 32, fewer SNPs than a
-tile, training sets smaller than a batch, batch sizes below 32 and between 33 and 64, no samples to
+tile, training sets smaller than a batch, batch sizes below 32 and between 33 and 128, no samples to
 predict."""
 import numpy as np
 import pytest
@@ -22,6 +22,9 @@ pytestmark = pytest.mark.gpu
     (5830, 256, 10, 48, 200),  # --batch_size 48 on the fixture's shape: second row block half full, last batch of 8
     (1000, 128, 6, 33, 100),   # --batch_size 33: one row spills into the second block; last batch of 1
     (700, 100, 5, 64, 64),     # exactly one full 64-row step per epoch; width 100 -> 128
+    (900, 256, 4, 128, 300),   # --batch_size 128: four row blocks, last batch of 44 (two blocks)
+    (400, 64, 6, 96, 200),     # --batch_size 96: three row blocks, last batch of 8
+    (2048, 128, 4, 100, 230),  # --batch_size 100: fourth block holds 4 rows; last batch of 30
 ])
 def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     """3 epochs of fit (eager epoch 0, captured graph afterwards) vs oracle.fit with the same init,
@@ -117,11 +120,11 @@ def test_unsupported_configurations_are_rejected_with_messages():
         LocatorNet(X, Y, 40, 64, 1)
     with pytest.raises(_lib.LocatorHipError, match="width"):
         LocatorNet(X, Y, 40, 600, 4)
-    # --batch_size: 1..64; above 32 only on the fused-stack widths up to 256 and with Dropout after layer >= 2
+    # --batch_size: 1..128; above 32 only on the fused-stack widths up to 256 and with Dropout after layer >= 2
     from locator_amd.train import EpochRunner
     tr, va = np.arange(6), np.arange(6, 8)
     with pytest.raises(ValueError, match="batch_size"):
-        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 65)
+        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 129)
     with pytest.raises(ValueError, match="batch_size"):
         EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 0)
     with pytest.raises(ValueError, match="width"):
