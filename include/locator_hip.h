@@ -192,7 +192,9 @@ int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int32_t* rows, 
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats
  * ([mean|var] of the NEXT minibatch, from loc_bn_epoch_stats) is non-NULL that kernel also writes the next
  * step's [scale|shift|mean|rstd] to bn4_out from the just-updated gamma/beta.  ev_after_main: optional
- * hipEvent_t recorded between the main kernel and the trailing per-SNP kernel (kernel timing). */
+ * hipEvent_t recorded between the main kernel and the trailing per-SNP kernel (kernel timing).
+ * n_b <= 32 rows per weight tile, or up to LOC_MAX_BATCH on the fused-stack widths 64/128/256: every tile then
+ * takes the gradient of all ceil(n_b/32) row blocks (dz1 rows [0, 32*ceil(n_b/32))) before its one Adam update. */
 int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                          const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
                          float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
@@ -276,7 +278,9 @@ int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const 
 
 /* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).
- * mask: n_b*Hp keep flags for this step (NULL iff drop_p == 0).  loss_out: 1 float.
+ * n_b <= 32, or <= LOC_MAX_BATCH when net->slot_rows = LOC_BATCH_SLOT (--batch_size > 32: needs the fused-stack
+ * widths 64/128/256, epoch-level BN statistics for steps of more than 32 rows, and Dropout not directly after layer 1).
+ * mask: keep flags for this step, [rows][Hp] with rows = 32*ceil(n_b/32) (NULL iff drop_p == 0).  loss_out: 1 float.
  * bn_ready != 0: this step's [scale|shift|mean|rstd] is already in the workspace (loc_bn_epoch_stats or the
  * previous step's bn_next_stats) and the per-step statistics kernel is skipped.
  * bn_next_stats: [mean|var] of the next minibatch or NULL (see loc_l1_backward_adam).
