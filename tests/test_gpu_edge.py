@@ -171,3 +171,10 @@ def test_speed_knobs_do_not_change_a_single_bit():
     assert _probe({"LOC_L1B_NT": "15"}) == ref
     assert _probe({"LOC_STACK_XCD_STRIDE": "1", "LOC_STACK_HELPERS": "0"}) == ref
     assert _probe({"LOC_STACK_HELPERS": "3"}) == ref
+    # opt-in experiments kept in the tree: the side-stream overlap only reorders launches ->
+    # identical bits; the split-K hidden stack changes the summation order -> same losses to 1e-5
+    assert _probe({"LOC_SIDE_STREAM": "1"}) == ref
+    split = _probe({"LOC_STACK_SPLIT": "4"})
+    a = np.array(eval(ref.split(" ", 2)[2]))
+    b = np.array(eval(split.split(" ", 2)[2]))
+    assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-5, (a, b)
