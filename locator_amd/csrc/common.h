@@ -7,6 +7,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __builtin_bit_cast(float, u); }
+// dword = { top16(lo) in bits 0..15, top16(hi) in bits 16..31 }: two bf16 values from two fp32 by truncation
+__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
 
 #define BN_EPS 1e-3f
 #define BN_MOMENTUM 0.99f

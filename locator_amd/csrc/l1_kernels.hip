@@ -330,6 +330,146 @@ __device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, f
     w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
 }
 
+template <int NHT, int NTM = 13>
+__global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
+    const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
+    const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
+    float* __restrict__ v1s, float* __restrict__ gbs, float* __restrict__ b1, float* __restrict__ m_b1,
+    float* __restrict__ v_b1, const float* __restrict__ alpha_tab, int alpha_tab_len,
+    const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
+    constexpr int Hp = NHT * 32;
+    constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dzl = smem;                                        // [32][PZ]
+    int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);      // [32]
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int jl = lane & 31, hi = lane >> 5;
+    const int nkt = Kp / KT;
+    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
+
+    for (int i = t; i < 32 * Hp; i += 256) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
+    if (t < 32) rows_l[t] = t < n_b ? rows[t] : 0;
+    __syncthreads();
+
+    // bias of layer 1: db1[h] = sum_b dZ[b][h]   (block 0 only)
+    if (blockIdx.x == 0) {
+        for (int ht = w; ht < NHT; ht += 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ht * 32 + jl];
+            s += __shfl_xor(s, 32);
+            if (hi == 0) {
+                int h = ht * 32 + jl;
+                float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
+                adam_update(wv, mv, vv, s, alpha);
+                b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
+            }
+        }
+    }
+
+    const int gw = blockIdx.x * 4 + w;
+    if (gw >= n_active) return;
+    const int64_t U = (int64_t)nkt * NHT;
+    const int u0 = (int)((int64_t)gw * U / n_active), u1 = (int)((int64_t)(gw + 1) * U / n_active);
+
+    const float* sc_p = bn4;
+    const float* sh_p = bn4 + Kp;
+    const float* mu_p = bn4 + 2 * (int64_t)Kp;
+    const float* rs_p = bn4 + 3 * (int64_t)Kp;
+
+    float xh[16], xn[16];
+    f32x16 dx = {0};
+    int cur_kt = -1, first_ht = 0;
+
+    auto flush = [&](int kt, int last_ht) {
+        float pg = 0.f, pb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pg = fmaf(dx[r], xn[r], pg);
+            pb += dx[r];
+        }
+        pg += __shfl_xor(pg, 32);
+        pb += __shfl_xor(pb, 32);
+        if (hi == 0) {
+            float* g0 = gbs + (int64_t)kt * 128;   // [slot][2][32]
+            if (first_ht == 0) {
+                g0[jl] = pg; g0[32 + jl] = pb;
+                if (last_ht == NHT - 1) { g0[64 + jl] = 0.f; g0[96 + jl] = 0.f; }
+            } else {
+                g0[64 + jl] = pg; g0[96 + jl] = pb;
+            }
+        }
+    };
+    auto load_unit = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
+        const int64_t base = (int64_t)u * 1024;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w1s + base);
+        const f32x4* mp = reinterpret_cast<const f32x4*>(m1s + base);
+        const f32x4* vp = reinterpret_cast<const f32x4*>(v1s + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wq[q] = (NTM & 2) ? __builtin_nontemporal_load(wp + q * 64 + lane) : wp[q * 64 + lane];
+            mq[q] = (NTM & 1) ? __builtin_nontemporal_load(mp + q * 64 + lane) : mp[q * 64 + lane];
+            vq[q] = (NTM & 1) ? __builtin_nontemporal_load(vp + q * 64 + lane) : vp[q * 64 + lane];
+        }
+    };
+    auto step = [&](int u, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4], f32x4 (&wn)[4], f32x4 (&mn)[4],
+                    f32x4 (&vn)[4]) {
+        const int kt = u / NHT, ht = u - kt * NHT;
+        if (kt != cur_kt) {   // wave-uniform
+            if (cur_kt >= 0) flush(cur_kt, NHT - 1);
+            const int k = kt * KT + jl;
+            const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k], rs = rs_p[k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int b = rowmap(r, hi);
+                float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
+                bool ok = b < n_b;
+                xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
+                xn[r] = ok ? (xv - mu) * rs : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+            cur_kt = kt;
+            first_ht = ht;
+        }
+        if (u + 1 < u1) load_unit(u + 1, wn, mn, vn);
+        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
+        f32x16 g = {0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ht * 32 + jl], xh[s], g);
+        // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dx = mfma32(dzl[jl * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
+        const int64_t base = (int64_t)u * 1024;
+        f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
+        f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
+        f32x4* vp = reinterpret_cast<f32x4*>(v1s + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
+                adam_update_fast(wv, mv, vv, g[q * 4 + c], alpha);
+                wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
+            }
+            if (NTM & 4) __builtin_nontemporal_store(wq[q], wp + q * 64 + lane); else wp[q * 64 + lane] = wq[q];
+            if (NTM & 8) __builtin_nontemporal_store(mq[q], mp + q * 64 + lane); else mp[q * 64 + lane] = mq[q];
+            if (NTM & 8) __builtin_nontemporal_store(vq[q], vp + q * 64 + lane); else vp[q * 64 + lane] = vq[q];
+        }
+    };
+
+    if (u0 < u1) {
+        f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
+        load_unit(u0, wA, mA, vA);
+        for (int u = u0; u < u1; u += 2) {
+            step(u, wA, mA, vA, wB, mB, vB);
+            if (u + 1 < u1) step(u + 1, wB, mB, vB, wA, mA, vA);
+        }
+        flush(cur_kt, (u1 - 1) % NHT);
+    }
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), so that register arrays
 // indexed by the row block never degrade to scratch memory when the unroller gives up
 template <int N, class F>
@@ -340,55 +480,76 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// RB = row blocks of 32 the kernel is built for (--batch_size <= 32*RB); RB = 1 is the default path.  With
-// RB > 1 every weight tile takes the gradient of all row blocks before its single Adam update (the step is
-// linear in the rows: BatchNorm is the first layer, its batch statistics depend on the data only), at
-// unchanged weight traffic.  To stay inside the register file the RB > 1 build keeps the genotypes of a
-// k-tile as packed bytes and re-derives xhat / xn when an MFMA needs them.
-// Workgroup: 4 waves, two workgroups per CU (RB <= 2); with RB >= 3 the dz image leaves room for one
-// workgroup per CU only, so it carries all 8 waves (the stream needs ~190 KB in flight per CU).
-template <int NHT, int NTM = 13, int RB = 1>
-__global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_adam_kernel(
+// ---------------------------------------------------------------------------------------------
+// Layer-1 backward + Adam for MORE than 32 rows (--batch_size 33..128: RB = 2..4 row blocks of 32).
+//
+// With RB row blocks the fp32-MFMA formulation above needs 32*RB MFMAs of 64 cycles per 12 KB of weight
+// stream and turns matrix-bound at RB >= 3.  This kernel removes almost all of that work, exactly:
+//   * xhat = x*s_k + t_k with x a uint8 genotype, so
+//         dW^T[h][k] = s_k * S[h][k] + t_k * dzsum[h],   S[h][k] = sum_b dz[b][h] x[b][k],  dzsum[h] = sum_b dz[b][h].
+//     x is exact in bf16 and dz splits exactly into three bf16 pieces (truncation, 8+8+8 significand bits), so S
+//     is three v_mfma_f32_32x32x16_bf16 per 16 rows with exact products and fp32 accumulation;
+//   * BatchNorm's gamma/beta gradients need sum_b dxhat*xn and sum_b dxhat with dxhat = dz W^T; pushing the sum
+//     over b inside gives   sum_h W[h][k] * rstd_k (S[h][k] - mu_k dzsum[h])   and   sum_h W[h][k] dzsum[h]
+//     -- per-lane reductions over the accumulator the wave already holds (lane = SNP k), so dxhat is never formed
+//     and its MFMAs disappear.
+// Per unit: 6*RB bf16 MFMAs of 32 cycles instead of 32*RB fp32 MFMAs of 64.  dz lives in LDS transposed,
+// [unit][row] fp32 (33 KB per row block at width 256), so RB = 2 keeps two 4-wave workgroups per CU and
+// RB = 3, 4 run one 8-wave workgroup.  Same work partition, cache policy, gamma/beta hand-off (gbs slots) and
+// Adam arithmetic as l1_bwd_adam_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int NHT, int NTM, int RB>
+__global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_adam_rows_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
     float* __restrict__ v1s, float* __restrict__ gbs, float* __restrict__ b1, float* __restrict__ m_b1,
     float* __restrict__ v_b1, const float* __restrict__ alpha_tab, int alpha_tab_len,
     const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
     constexpr int Hp = NHT * 32;
-    constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
+    constexpr int NR = 32 * RB;                 // rows the workgroup is built for
+    constexpr int PT = NR + 4;                  // pitch of dzT rows (floats): 16-B aligned, banks shifted by 4 per unit
+    constexpr int NQ = 2 * RB;                  // 16-row MFMA blocks
     constexpr int NT = RB > 2 ? 512 : 256, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dzl = smem;                                             // [32*RB][PZ]
-    int* rows_l = reinterpret_cast<int*>(dzl + 32 * RB * PZ);      // [32*RB]
+    float* dzT = smem;                                              // [Hp][PT]   dz transposed: [unit][row]
+    float* dzsum = dzT + Hp * PT;                                   // [Hp]
+    int* rows_l = reinterpret_cast<int*>(dzsum + Hp);               // [NR]
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
     const int nkt = Kp / KT;
-    const int nrb = RB == 1 ? 1 : (n_b + 31) / 32;                 // row blocks in use (wave-uniform)
+    // the launcher picks RB = ceil(n_b / 32), so all NR rows are in use; dz rows n_b..NR-1 are zero
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
 
-    for (int i = t; i < 32 * nrb * Hp; i += NT) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
-    if (t < 32 * RB) rows_l[t] = t < n_b ? rows[t] : 0;
+    // dz1 is [row][unit]; the MFMA A operand wants [unit][row].  Lanes run along the rows (conflict-free LDS
+    // stores; the 16-byte global reads of different rows all hit L2, dz1 is 32*RB KB)
+    for (int i = t; i < NR * (Hp / 4); i += NT) {
+        const int r = i % NR, hq = i / NR;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dz1 + (int64_t)r * Hp + 4 * hq);
+        dzT[(4 * hq + 0) * PT + r] = v[0];
+        dzT[(4 * hq + 1) * PT + r] = v[1];
+        dzT[(4 * hq + 2) * PT + r] = v[2];
+        dzT[(4 * hq + 3) * PT + r] = v[3];
+    }
+    if (t < NR) rows_l[t] = t < n_b ? rows[t] : 0;
+    __syncthreads();
+    for (int h = t; h < Hp; h += NT) {          // 16-byte reads: one unit per lane, PT = 4 mod 64 -> conflict-free
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int r = 0; r < NR; r += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dzT + h * PT + r);
+            s4[0] += v[0]; s4[1] += v[1]; s4[2] += v[2]; s4[3] += v[3];
+        }
+        dzsum[h] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
     __syncthreads();
 
     // bias of layer 1: db1[h] = sum_b dZ[b][h]   (block 0 only)
     if (blockIdx.x == 0) {
-        for (int ht = w; ht < NHT; ht += NW) {
-            float s = 0.f;
-            static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
-                constexpr int rb = decltype(RBI)::value;
-                if (rb < nrb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += dzl[(32 * rb + rowmap(r, hi)) * PZ + ht * 32 + jl];
-                }
-            });
-            s += __shfl_xor(s, 32);
-            if (hi == 0) {
-                int h = ht * 32 + jl;
-                float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
-                adam_update(wv, mv, vv, s, alpha);
-                b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
-            }
+        for (int h = t; h < Hp; h += NT) {
+            float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
+            adam_update(wv, mv, vv, dzsum[h], alpha);
+            b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
         }
     }
 
@@ -402,52 +563,23 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
     const float* mu_p = bn4 + 2 * (int64_t)Kp;
     const float* rs_p = bn4 + 3 * (int64_t)Kp;
 
-    // genotypes of the current k-tile for this lane's SNP: rows rowmap(r, hi) + 32*rb.
-    // RB == 1: xhat / xn kept as floats (as tuned); RB > 1: packed bytes + the four BN scalars.
-    float xh[RB == 1 ? 16 : 1], xn[RB == 1 ? 16 : 1];
-    uint32_t xb[RB == 1 ? 1 : RB][4];
-    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f;
-    auto xhat = [&](int rb, int r) __attribute__((always_inline)) -> float {
-        if constexpr (RB == 1) return xh[r];
-        else {
-            const bool ok = 32 * rb + rowmap(r, hi) < n_b;
-            const float xv = (float)((xb[rb][r >> 2] >> (8 * (r & 3))) & 255u);
-            return ok ? fmaf(xv, k_sc, k_sh) : 0.f;
-        }
-    };
-    auto xnorm = [&](int rb, int r) __attribute__((always_inline)) -> float {
-        if constexpr (RB == 1) return xn[r];
-        else {
-            const bool ok = 32 * rb + rowmap(r, hi) < n_b;
-            const float xv = (float)((xb[rb][r >> 2] >> (8 * (r & 3))) & 255u);
-            return ok ? (xv - k_mu) * k_rs : 0.f;
-        }
-    };
-    f32x16 dx[RB];
-    static_for<RB>([&](auto RBI) __attribute__((always_inline)) { dx[decltype(RBI)::value] = f32x16{0}; });
+    // genotypes of the current k-tile for this lane's SNP as the MFMA B operand: block q holds rows
+    // 16q + 8hi + 0..7 as eight bf16 values
+    u32x4 xq[NQ];
+    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f, pg = 0.f, pb = 0.f;
     int cur_kt = -1, first_ht = 0;
 
     auto flush = [&](int kt, int last_ht) __attribute__((always_inline)) {
-        float pg = 0.f, pb = 0.f;
-        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
-            constexpr int rb = decltype(RBI)::value;
-            if (rb < nrb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pg = fmaf(dx[rb][r], xnorm(rb, r), pg);
-                    pb += dx[rb][r];
-                }
-            }
-        });
-        pg += __shfl_xor(pg, 32);
-        pb += __shfl_xor(pb, 32);
+        float g_ = pg * k_rs, b_ = pb;
+        g_ += __shfl_xor(g_, 32);
+        b_ += __shfl_xor(b_, 32);
         if (hi == 0) {
             float* g0 = gbs + (int64_t)kt * 128;   // [slot][2][32]
             if (first_ht == 0) {
-                g0[jl] = pg; g0[32 + jl] = pb;
+                g0[jl] = g_; g0[32 + jl] = b_;
                 if (last_ht == NHT - 1) { g0[64 + jl] = 0.f; g0[96 + jl] = 0.f; }
             } else {
-                g0[64 + jl] = pg; g0[96 + jl] = pb;
+                g0[64 + jl] = g_; g0[96 + jl] = b_;
             }
         }
     };
@@ -469,53 +601,47 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
         if (kt != cur_kt) {   // wave-uniform
             if (cur_kt >= 0) flush(cur_kt, NHT - 1);
             const int k = kt * KT + jl;
-            const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k], rs = rs_p[k];
-            if constexpr (RB == 1) {
+            k_sc = sc_p[k]; k_sh = sh_p[k]; k_mu = mu_p[k]; k_rs = rs_p[k];
+            static_for<NQ>([&](auto QI) __attribute__((always_inline)) {
+                constexpr int q = decltype(QI)::value;
+                float xv[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int b = rowmap(r, hi);
-                    float xv = (float)X[(int64_t)rows_l[b] * pitch + k];
-                    bool ok = b < n_b;
-                    xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
-                    xn[r] = ok ? (xv - mu) * rs : 0.f;
-                }
-            } else {
-                k_sc = sc; k_sh = sh; k_mu = mu; k_rs = rs;
-                static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
-                    constexpr int rb = decltype(RBI)::value;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xb[rb][q] = 0u;
-                    if (rb < nrb) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const uint32_t xv = X[(int64_t)rows_l[32 * rb + rowmap(r, hi)] * pitch + k];
-                            xb[rb][r >> 2] |= xv << (8 * (r & 3));
-                        }
-                    }
-                });
-            }
-            static_for<RB>([&](auto RBI) __attribute__((always_inline)) { dx[decltype(RBI)::value] = f32x16{0}; });
+                for (int i = 0; i < 8; ++i)
+                    xv[i] = (float)X[(int64_t)rows_l[16 * q + 8 * hi + i] * pitch + k];      // exact in bf16
+                xq[q][0] = pack_top16(fbits(xv[0]), fbits(xv[1]));
+                xq[q][1] = pack_top16(fbits(xv[2]), fbits(xv[3]));
+                xq[q][2] = pack_top16(fbits(xv[4]), fbits(xv[5]));
+                xq[q][3] = pack_top16(fbits(xv[6]), fbits(xv[7]));
+            });
+            pg = 0.f; pb = 0.f;
             cur_kt = kt;
             first_ht = ht;
         }
         if (u + 1 < u1) load_unit(u + 1, wn, mn, vn);
-        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = 32*rb + rowmap(s, hi)
-        f32x16 g = {0};
-        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
-            constexpr int rb = decltype(RBI)::value;
-            if (rb < nrb) {
+        // S[h][k] = sum_b dz[b][h] x[b][k]: D[i = unit][j = SNP], 16 rows per MFMA, three exact bf16 pieces of dz
+        f32x16 S = {0};
+        const float* arow = dzT + (ht * 32 + jl) * PT + 8 * hi;
+        static_for<NQ>([&](auto QI) __attribute__((always_inline)) {
+            constexpr int q = decltype(QI)::value;
+            {
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(arow + 16 * q);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(arow + 16 * q + 4);
+                float v[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                const bf16x8 b = __builtin_bit_cast(bf16x8, xq[q]);
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    g = mfma32(dzl[(32 * rb + rowmap(s, hi)) * PZ + ht * 32 + jl], xhat(rb, s), g);
-            }
-        });
-        // dxhat tile: D[i = row b][j = SNP], contraction over units h = ht*32 + rowmap(s, hi)
-        static_for<RB>([&](auto RBI) __attribute__((always_inline)) {
-            constexpr int rb = decltype(RBI)::value;
-            if (rb < nrb) {
+                for (int p = 0; p < 3; ++p) {
+                    u32x4 a;
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    dx[rb] = mfma32(dzl[(32 * rb + jl) * PZ + ht * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx[rb]);
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo = fbits(v[2 * e]), hh = fbits(v[2 * e + 1]);
+                        a[e] = pack_top16(lo, hh);
+                        if (p < 2) {
+                            v[2 * e] -= bitsf(lo & 0xFFFF0000u);
+                            v[2 * e + 1] -= bitsf(hh & 0xFFFF0000u);
+                        }
+                    }
+                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, S, 0, 0, 0);
+                }
             }
         });
         const int64_t base = (int64_t)u * 1024;
@@ -524,10 +650,16 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
         f32x4* vp = reinterpret_cast<f32x4*>(v1s + base);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            // accumulator rows 4q..4q+3 are units ht*32 + 8q + 4hi + 0..3: their dz sums are one 16-byte read
+            const f32x4 ds4 = *reinterpret_cast<const f32x4*>(dzsum + ht * 32 + 8 * q + 4 * hi);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                const float s_ = S[q * 4 + c], ds = ds4[c];
                 float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
-                adam_update_fast(wv, mv, vv, g[q * 4 + c], alpha);
+                pg = fmaf(wv, fmaf(-k_mu, ds, s_), pg);          // sum_h W (S - mu dzsum); rstd applied at the flush
+                pb = fmaf(wv, ds, pb);
+                const float g = fmaf(k_sc, s_, k_sh * ds);
+                adam_update_fast(wv, mv, vv, g, alpha);
                 wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
             }
             if (NTM & 4) __builtin_nontemporal_store(wq[q], wp + q * 64 + lane); else wp[q * 64 + lane] = wq[q];
@@ -671,15 +803,16 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     if (n_active > nkt) n_active = nkt;
     grid = (n_active + 3) / 4;
     const int rb = (n_b + LOC_ROWS - 1) / LOC_ROWS;
-    const size_t lds = ((size_t)32 * rb * (d->Hp + 1) + 32 * rb) * sizeof(float);
+    const size_t lds = rb == 1 ? ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float)
+                               : ((size_t)d->Hp * (32 * rb + 4) + d->Hp + 32 * rb) * sizeof(float);
     if (rb > 1) {
         // more than 32 rows: RB row blocks per weight tile (widths of the fused hidden stack up to 256 only).
         // RB = 2 keeps two workgroups per CU (66 KB of dz each at width 256); RB = 3, 4 run one per CU.
 #define LAUNCH_BWD_RB(N, R)                                                                                    \
     {                                                                                                          \
         static size_t lds_set = 0;                                                                             \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N, 13, R>, lds); if (rc) return rc; lds_set = lds; } \
-        hipLaunchKernelGGL((l1_bwd_adam_kernel<N, 13, R>), dim3(R > 2 ? (n_active + 7) / 8 : grid),              \
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_rows_kernel<N, 13, R>, lds); if (rc) return rc; lds_set = lds; } \
+        hipLaunchKernelGGL((l1_bwd_adam_rows_kernel<N, 13, R>), dim3(R > 2 ? (n_active + 7) / 8 : grid),         \
                            dim3(R > 2 ? 512 : 256), lds, (hipStream_t)stream, X, x_pitch,                      \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \

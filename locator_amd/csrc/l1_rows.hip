@@ -35,16 +35,9 @@
 
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KT 32
 
-__device__ __forceinline__ uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
-__device__ __forceinline__ float bitsf(uint32_t u) { return __builtin_bit_cast(float, u); }
-// dword = { top16(lo) in bits 0..15, top16(hi) in bits 16..31 }
-__device__ __forceinline__ uint32_t pack_top16(uint32_t lo, uint32_t hi) {
-    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-}
 __device__ __forceinline__ uint32_t rne16(uint32_t u) { return u + 0x7FFFu + ((u >> 16) & 1u); }
 __device__ __forceinline__ float lane_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
