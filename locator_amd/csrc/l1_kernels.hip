@@ -485,12 +485,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 //
 // With RB row blocks the fp32-MFMA formulation above needs 32*RB MFMAs of 64 cycles per 12 KB of weight
 // stream and turns matrix-bound at RB >= 3.  This kernel removes almost all of that work, exactly:
-//   * xhat = x*s_k + t_k with x a uint8 genotype, so
-//         dW^T[h][k] = s_k * S[h][k] + t_k * dzsum[h],   S[h][k] = sum_b dz[b][h] x[b][k],  dzsum[h] = sum_b dz[b][h].
-//     x is exact in bf16 and dz splits exactly into three bf16 pieces (truncation, 8+8+8 significand bits), so S
-//     is three v_mfma_f32_32x32x16_bf16 per 16 rows with exact products and fp32 accumulation;
+//   * xhat = s_k (x - c_k) + (t_k + s_k c_k) with x a uint8 genotype and c_k = rint(batch mean), so
+//         dW^T[h][k] = s_k S[h][k] + (t_k + s_k c_k) dzsum[h],  S[h][k] = sum_b dz[b][h] (x[b][k] - c_k),
+//         dzsum[h] = sum_b dz[b][h].
+//     x - c is a small integer, exact in bf16, and dz splits exactly into three bf16 pieces (truncation, 8+8+8
+//     significand bits), so S is three v_mfma_f32_32x32x16_bf16 per 16 rows with exact products and fp32
+//     accumulation; centring on c keeps both terms at the size of the result (no cancellation);
 //   * BatchNorm's gamma/beta gradients need sum_b dxhat*xn and sum_b dxhat with dxhat = dz W^T; pushing the sum
-//     over b inside gives   sum_h W[h][k] * rstd_k (S[h][k] - mu_k dzsum[h])   and   sum_h W[h][k] dzsum[h]
+//     over b inside gives   sum_h W[h][k] * rstd_k (S[h][k] - (mu_k - c_k) dzsum[h])   and   sum_h W[h][k] dzsum[h]
 //     -- per-lane reductions over the accumulator the wave already holds (lane = SNP k), so dxhat is never formed
 //     and its MFMAs disappear.
 // Per unit: 6*RB bf16 MFMAs of 32 cycles instead of 32*RB fp32 MFMAs of 64.  dz lives in LDS transposed,
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
     // genotypes of the current k-tile for this lane's SNP as the MFMA B operand: block q holds rows
     // 16q + 8hi + 0..7 as eight bf16 values
     u32x4 xq[NQ];
-    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f, pg = 0.f, pb = 0.f;
+    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f, k_c = 0.f, pg = 0.f, pb = 0.f;
     int cur_kt = -1, first_ht = 0;
 
     auto flush = [&](int kt, int last_ht) __attribute__((always_inline)) {
@@ -601,13 +603,21 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
         if (kt != cur_kt) {   // wave-uniform
             if (cur_kt >= 0) flush(cur_kt, NHT - 1);
             const int k = kt * KT + jl;
-            k_sc = sc_p[k]; k_sh = sh_p[k]; k_mu = mu_p[k]; k_rs = rs_p[k];
+            // Genotypes are centred on the integer nearest the batch mean, c_k = rint(mu_k): x - c_k is still an
+            // exact bf16 integer, and xhat = s (x - c) + (t + s c) leaves two terms of the size of the result
+            // instead of two large ones that cancel (t = beta - mu s):  k_sh, k_mu hold t + s c and mu - c.
+            {
+                const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k];
+                const float c = rintf(mu);
+                k_sc = sc; k_sh = fmaf(sc, c, sh); k_mu = mu - c; k_rs = rs_p[k];
+                k_c = c;
+            }
             static_for<NQ>([&](auto QI) __attribute__((always_inline)) {
                 constexpr int q = decltype(QI)::value;
                 float xv[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    xv[i] = (float)X[(int64_t)rows_l[16 * q + 8 * hi + i] * pitch + k];      // exact in bf16
+                for (int i = 0; i < 8; ++i)      // small integers: exact in bf16
+                    xv[i] = (float)X[(int64_t)rows_l[16 * q + 8 * hi + i] * pitch + k] - k_c;
                 xq[q][0] = pack_top16(fbits(xv[0]), fbits(xv[1]));
                 xq[q][1] = pack_top16(fbits(xv[2]), fbits(xv[3]));
                 xq[q][2] = pack_top16(fbits(xv[4]), fbits(xv[5]));
@@ -805,6 +815,18 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     const int rb = (n_b + LOC_ROWS - 1) / LOC_ROWS;
     const size_t lds = rb == 1 ? ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float)
                                : ((size_t)d->Hp * (32 * rb + 4) + d->Hp + 32 * rb) * sizeof(float);
+    static int rows1 = -1;      // LOC_L1B_ROWS=1: the bf16x3 row-block kernel also for <= 32 rows (measurement knob)
+    if (rows1 < 0) { const char* e = getenv("LOC_L1B_ROWS"); rows1 = e ? atoi(e) : 0; }
+    if (rb == 1 && rows1 && nht == 8) {
+        const size_t lds = ((size_t)d->Hp * 36 + d->Hp + 32) * sizeof(float);
+        static size_t lds_set = 0;
+        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_rows_kernel<8, 13, 1>, lds); if (rc) return rc; lds_set = lds; }
+        hipLaunchKernelGGL((l1_bwd_adam_rows_kernel<8, 13, 1>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X,
+                           x_pitch, rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);
+        LOC_CHECK_LAUNCH();
+        return 0;
+    }
     if (rb > 1) {
         // more than 32 rows: RB row blocks per weight tile (widths of the fused hidden stack up to 256 only).
         // RB = 2 keeps two workgroups per CU (66 KB of dz each at width 256); RB = 3, 4 run one per CU.

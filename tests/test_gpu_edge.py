@@ -178,3 +178,18 @@ def test_speed_knobs_do_not_change_a_single_bit():
     a = np.array(eval(ref.split(" ", 2)[2]))
     b = np.array(eval(split.split(" ", 2)[2]))
     assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-5, (a, b)
+
+
+def test_row_block_backward_meets_the_single_step_parity_bar():
+    """The bf16x3 row-block backward (normally used above 32 rows) pushed through the strictest parity tests of
+    the default kernel: LOC_L1B_ROWS=1 routes <= 32-row steps of width 256 through it as one row block.  One
+    training step within 1e-5 of the fp64 oracle on every weight, five steps, and the golden fixtures."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_golden.py", "-m", "gpu",
+                        "-q", "-x", "-p", "no:cacheprovider", "-k", "one_training_step or five_steps or hip_path"],
+                       cwd=root, env=dict(os.environ, LOC_L1B_ROWS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
