@@ -317,6 +317,8 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         return;
     }
     __shared__ float gt[32][33];
+    __shared__ float gtp[RB > 1 ? RB : 1][32][33];      // per-row-block partial tiles (RB > 1)
+    __shared__ float sbp[RB > 1 ? RB : 1][32];
     __shared__ float hsm[32 * RB][8];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
     const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;
@@ -343,33 +345,71 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
             idx[i] = (int64_t)(kt * 32 + (e >> 5)) * Hp + nt * 32 + (e & 31);
             wv[i] = W2[idx[i]]; mv[i] = mW2[idx[i]]; vv[i] = vW2[idx[i]];
         }
-        if (w == 0) {
-            f32x16 g = {0};
-            float sb = 0.f;
-#pragma unroll
-            for (int rb = 0; rb < nrb; ++rb) {
+        if constexpr (RB == 1) {
+            if (w == 0) {
                 float av[16], bv[16];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const int b = 32 * rb + 2 * s + hi;
+                    const int b = 2 * s + hi;
                     av[s] = in2[b * Hp + kt * 32 + jl];
                     bv[s] = dz2[b * Hp + nt * 32 + jl];
                 }
+                f32x16 g = {0};
 #pragma unroll
                 for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sb += bv[i];
-            }
+                for (int r = 0; r < 16; ++r) gt[rowmap(r, hi)][jl] = g[r];
+                if (kt == 0) {
+                    float sb = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gt[rowmap(r, hi)][jl] = g[r];
-            if (kt == 0) {
-                sb += __shfl_xor(sb, 32);
-                if (hi == 0) {
-                    const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + jl;
-                    float bw = P[o], bm = M[o], bvv = V[o];
-                    adam_update(bw, bm, bvv, sb, alpha);
-                    P[o] = bw; M[o] = bm; V[o] = bvv;
+                    for (int i = 0; i < 16; ++i) sb += bv[i];
+                    sb += __shfl_xor(sb, 32);
+                    if (hi == 0) {
+                        const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + jl;
+                        float bw = P[o], bm = M[o], bvv = V[o];
+                        adam_update(bw, bm, bvv, sb, alpha);
+                        P[o] = bw; M[o] = bm; V[o] = bvv;
+                    }
                 }
+            }
+        } else {
+            // one wave per row block (their load latencies overlap); the RB partial tiles are added in a fixed order
+            if (w < RB) {
+                float av[16], bv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int b = 32 * w + 2 * s + hi;
+                    av[s] = in2[b * Hp + kt * 32 + jl];
+                    bv[s] = dz2[b * Hp + nt * 32 + jl];
+                }
+                f32x16 g = {0};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gtp[w][rowmap(r, hi)][jl] = g[r];
+                float sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sb += bv[i];
+                sb += __shfl_xor(sb, 32);
+                if (hi == 0) sbp[w][jl] = sb;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = t + 512 * i;
+                float a = gtp[0][e >> 5][e & 31];
+#pragma unroll
+                for (int rb = 1; rb < RB; ++rb) a += gtp[rb][e >> 5][e & 31];
+                gt[e >> 5][e & 31] = a;
+            }
+            if (kt == 0 && t < 32) {
+                float sb = sbp[0][t];
+#pragma unroll
+                for (int rb = 1; rb < RB; ++rb) sb += sbp[rb][t];
+                const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + t;
+                float bw = P[o], bm = M[o], bvv = V[o];
+                adam_update(bw, bm, bvv, sb, alpha);
+                P[o] = bw; M[o] = bm; V[o] = bvv;
             }
         }
         __syncthreads();
