@@ -12,15 +12,23 @@ def make_problem(n, K, width, nlayers, seed=0, n_na=0):
     w = rng.normal(0, 1, (K, 2)) / np.sqrt(K)
     y = (x - x.mean(0)) @ w
     y = (y - y.mean(0)) / y.std(0)
-    p = O.init_params(K, width, nlayers, rng)
-    # make every tensor non-trivial so a dropped term cannot hide
+    p = randomize_params(O.init_params(K, width, nlayers, rng), rng, round_fp32=False)
+    return x, y, p, rng
+
+
+def randomize_params(p, rng, round_fp32=True):
+    """Make every tensor non-trivial so a dropped term cannot hide.  round_fp32: keep the fp64 oracle's starting
+    point exactly representable in fp32, so both sides start from identical values."""
+    K = p["gamma"].shape[0]
     p["gamma"] = rng.uniform(0.7, 1.3, K)
     p["beta"] = rng.normal(0, 0.05, K)
     p["mov_mean"] = rng.uniform(0, 1, K)
     p["mov_var"] = rng.uniform(0.2, 1.2, K)
     for l in range(len(p["b"])):
         p["b"][l] = rng.normal(0, 0.05, p["b"][l].shape)
-    return x, y, p, rng
+    if round_fp32:
+        p = O.cast_params(O.cast_params(p, np.float32), np.float64)
+    return p
 
 
 def build_net(x, y, p, drop_p=0.25, seed=1):
