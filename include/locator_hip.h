@@ -187,6 +187,20 @@ int loc_l1_rows_supported(int Hp, int pieces);
 int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                         const float* scale_shift, const float* w1s, const float* b1, float* partial,
                         int64_t partial_floats, float* a1, int pieces, int target_blocks, void* stream);
+/* The same contraction for MANY rows with the weight conversion taken out of the K loop (model.predict over all
+ * samples, locator.py:414, :441; the --jacknife replicate predictions, :683-747): loc_l1_image_build streams W1S once
+ * into `image` -- bf16 tiles of s_k*W1 (`pieces` per weight, 3 = exact) laid out as the GEMM's LDS tiles, plus the
+ * per-unit shift term sum_k t_k W1[k][h] -- and loc_l1_forward_gemm multiplies any number of row sets against it on
+ * the bf16 matrix pipe (u8 -> bf16 genotype widening is the only vector work in its K loop).  The image is valid
+ * until W1, gamma/beta or the BatchNorm statistics change.  Padded width 256 only (loc_l1_gemm_supported);
+ * loc_l1_image_bytes = size of `image`.  partial / partial_floats / a1 / target_blocks as for loc_l1_forward_rows. */
+int loc_l1_gemm_supported(int Hp, int pieces);
+int64_t loc_l1_image_bytes(const loc_dims* d, int pieces);
+int loc_l1_image_build(const loc_dims* d, const float* scale_shift, const float* w1s, int pieces, void* image,
+                       void* stream);
+int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
+                        const void* image, int pieces, const float* b1, float* partial, int64_t partial_floats,
+                        float* a1, int target_blocks, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats

@@ -75,6 +75,46 @@ def main():
                        "gbs": round(byts / us * 1e-3, 1), "frac_hbm_peak": round(byts / us * 1e-3 / HBM_PEAK_GBS, 4)}
                 print(json.dumps(rec), flush=True)
                 out.append(rec)
+    # image-based GEMM (l1_gemm.hip): conversion once per sweep, then a pure matrix-pipe K loop
+    for n in [int(r) for r in a.rows.split(",")]:
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
+        for pieces in (3, 2, 1):
+            if not lib.loc_l1_gemm_supported(d.Hp, pieces):
+                continue
+            image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
+
+            def prep():
+                _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
+                                                  image.data_ptr(), None))
+
+            def run():
+                _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
+                                                   image.data_ptr(), pieces, P + 4 * lay.b1, partial.data_ptr(),
+                                                   256 * 128 * d.Hp, a1.data_ptr(), 0, None))
+            t = {}
+            for name, fn in (("prep", prep), ("gemm", run)):
+                for _ in range(5):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+            flops = 2.0 * n * a.snps * a.width
+            byts = n * a.snps + 2.0 * pieces * a.snps * a.width
+            rec = {"kernel": "image+gemm", "rows": n, "snps": a.snps, "width": a.width, "pieces": pieces,
+                   "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
+                   "tflops": round(flops / t["gemm"] * 1e-6, 1),
+                   "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                   "frac_bf16_peak_incl_prep": round(flops / (t["gemm"] + t["prep"]) * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                   "mfma_issue_frac": round(pieces * flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                   "gbs": round(byts / t["gemm"] * 1e-3, 1)}
+            print(json.dumps(rec), flush=True)
+            out.append(rec)
     return out
 
 

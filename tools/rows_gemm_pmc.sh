@@ -23,12 +23,12 @@ for d in ("rows_pmc1", "rows_pmc2"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if "l1_rows" in k or "l1_reduce" in k:
+            if "l1_rows" in k or "l1_reduce" in k or "l1_gemm" in k or "l1_image" in k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             out["kernels"].setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 for k, v in out["kernels"].items():
-    if "l1_rows" in k and "SQ_WAVE_CYCLES" in v:
+    if ("l1_rows" in k or "l1_gemm_kernel" in k) and "SQ_WAVE_CYCLES" in v:
         waves = 2048.0
         cyc = 4 * v["SQ_WAVE_CYCLES"] / waves
         v["derived"] = {"cycles_per_wave": cyc,
@@ -42,4 +42,4 @@ for k, v in out["kernels"].items():
     if "derived" in v:
         print(k, json.dumps(v["derived"]))
 PY
-grep -E "l1_rows|l1_reduce" $O/rows_kt/k_kernel_stats.csv | cut -c1-160
+grep -E "l1_rows|l1_reduce|l1_gemm|l1_image" $O/rows_kt/k_kernel_stats.csv | cut -c1-160
