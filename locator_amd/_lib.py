@@ -63,6 +63,7 @@ SIGNATURES = {
     "loc_l1_image_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_l1_forward_gemm": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, vp, vp, C.c_int64, vp,
                                       C.c_int, vp]),
+    "loc_l1_gemm_debug_read": (C.c_int, [vp]),
     "loc_l1_backward_adam_main": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,

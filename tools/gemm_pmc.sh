@@ -1,0 +1,40 @@
+#!/bin/bash
+# PMC passes on tools/gemm_variants.py (GPU box, repo root): bash tools/gemm_pmc.sh "<variant list>" [pieces]
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+V=${1:-0}
+PZ=${2:-1,3}
+rm -rf $O/gp1 $O/gp2 $O/gp3
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $O/gp1 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $O/gp2 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL -d $O/gp3 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp3.log 2>&1
+python3 - <<PY
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("gp1", "gp2", "gp3"):
+    for f in glob.glob("$O/" + d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "l1_gemm" in k and "reduce" not in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, v in acc.items():
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    waves = 2048.0
+    if "SQ_WAVE_CYCLES" in m:
+        cyc = 4 * m["SQ_WAVE_CYCLES"] / waves
+        f = lambda c: round(4 * m.get(c, 0) / (waves * cyc), 3)
+        m["derived"] = {"cycles_per_wave": round(cyc), "mfma_busy": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * cyc), 3),
+                        "wait_any(parked)": f("SQ_WAIT_ANY"), "wait_inst_any(issue stall)": f("SQ_WAIT_INST_ANY"), "active_inst_any": f("SQ_ACTIVE_INST_ANY"),
+                        "valu": f("SQ_ACTIVE_INST_VALU"), "lds_inst": f("SQ_ACTIVE_INST_LDS"), "vmem_inst": f("SQ_ACTIVE_INST_VMEM"), "sca": f("SQ_ACTIVE_INST_SCA"),
+                        "misc": f("SQ_ACTIVE_INST_MISC"), "wait_inst_lds": f("SQ_WAIT_INST_LDS"),
+                        "lds_array_busy": round(m.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc), 3), "lds_conflict": round(m.get("SQ_LDS_BANK_CONFLICT", 0) / max(m.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3),
+                        "insts_per_wave": {c: round(m.get(c, 0) / waves, 1) for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_IFETCH")},
+                        "level_vmem(avg outstanding x cycles)": m.get("SQ_INST_LEVEL_VMEM"), "level_lds": m.get("SQ_INST_LEVEL_LDS")}
+    out[k] = m
+json.dump(out, open("$O/gemm_pmc.json", "w"), indent=1)
+for k, m in out.items():
+    print(k, json.dumps(m.get("derived")))
+PY
+grep -iE "error|invalid|not found" $O/gp1.log $O/gp2.log $O/gp3.log | head -5

@@ -40,7 +40,16 @@ for pieces in [int(p) for p in a.pieces.split(",")]:
     image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
     for _ in range(3):
         _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces, image.data_ptr(), None))
+    ref = None
     for v in [int(x) for x in a.variants.split(",")]:
+        a1.fill_(float("nan"))
+        _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(), a.rows, C.byref(d),
+                                           image.data_ptr(), pieces, P + 4 * lay.b1, partial.data_ptr(),
+                                           partial.numel(), a1.data_ptr(), a.blocks | (v << 16), None))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = a1.clone()
+        print(f"pieces {pieces} variant {v}: max |a1 - a1(first variant)| = {(a1 - ref).abs().max().item():.3e}", flush=True)
         for _ in range(a.iters):
             _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(), a.rows, C.byref(d),
                                                image.data_ptr(), pieces, P + 4 * lay.b1, partial.data_ptr(),
