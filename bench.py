@@ -76,7 +76,8 @@ def l1_gemm_roofline(net, n_rows, iters=20):
         def run():
             _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
                                                C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
-                                               partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces, 0, None))
+                                               partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces, 0, None,
+                                               None))
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -12,9 +12,12 @@
  *   - every pointer is a DEVICE pointer unless the name starts with `h_`.
  *   - the caller owns every buffer; nothing here allocates or frees device memory.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no
- *     implicit synchronisation, no global mutable state: safe from several host
- *     threads / processes on different streams or devices.  Safe to capture
- *     into a hipGraph.
+ *     implicit synchronisation.  The library reads no environment variables and
+ *     keeps no settings: every speed hint is an explicit argument (loc_tuning).
+ *     The only process state is loc_last_error's thread-local message and, per
+ *     kernel and device, the largest dynamic-LDS limit already requested with
+ *     hipFuncSetAttribute (an idempotent cache).  Safe from several host threads
+ *     / processes on different streams or devices; safe to capture into a hipGraph.
  *   - return value: 0 = ok, otherwise a hipError_t (or -1 for a bad argument);
  *     loc_last_error() returns a thread-local message.
  *
@@ -77,6 +80,18 @@ typedef struct loc_layout {
     int64_t n_total;
 } loc_layout;
 
+/* Speed hints and measurement switches.  All-zero = defaults.  None of them changes a result beyond the summation
+ * order of a documented exact mode (tests/test_gpu_edge.py: bit-identical fits for every placement value). */
+typedef struct loc_tuning {
+    int stack_helpers;    /* L2 warm-up helper workgroups of the fused hidden stack: 0 = default (12), -1 = none   */
+    int stack_xcd_stride; /* 1, 2, 4 or 8: every n-th workgroup of the fused stack works, so the workers share
+                             8/n XCDs (observed block -> XCD = b % 8); 0 = default (8: one XCD)                     */
+    int l1b_nt_mask;      /* which Adam streams of the layer-1 backward are non-temporal (width 256): 9, 13, 15,
+                             -1 = none; 0 = default (13: moments and the W1 write-back)                             */
+    int l1b_rows;         /* 1: route <= 32-row steps of width 256 through the bf16x3 row-block backward           */
+    int rows_rt;          /* 8: 256-row tiles in loc_l1_forward_rows (width 256, even number of 128-row tiles)     */
+} loc_tuning;
+
 /* Everything a training / inference step needs.  All device pointers. */
 typedef struct loc_net {
     loc_dims d;
@@ -95,15 +110,6 @@ typedef struct loc_net {
                                 loc_stack_dw_adam; refresh with loc_transpose_hidden after loading weights) */
     /* workspace, sized by loc_workspace_floats() */
     float* ws;
-    /* optional overlap of the hidden-layer dW/Adam launch with the layer-1 backward: a second stream and two
-     * events (hipStream_t / hipEvent_t as void*), all NULL to stay on one stream */
-    void* side_stream;
-    void* ev_fork;
-    void* ev_join;
-    /* optional split-K hidden stack (LOC_STACK_SPLIT=4): zero-initialised hand-off buffer of
-     * loc_stack_split_bytes(Hp) bytes and a 1-int error word (set if a bounded spin times out) */
-    void* gran;
-    int* stack_err;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
     int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32), or
@@ -111,7 +117,13 @@ typedef struct loc_net {
     int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
                                 32-row fp32-MFMA kernel for every block of rows                          */
+    void* l1_image;          /* optional: loc_l1_image_bytes(d, pieces) bytes of scratch.  When set, loc_predict over
+                                at least LOC_GEMM_MIN_ROWS rows converts W1 once per call (loc_l1_image_build) and
+                                runs every row chunk through loc_l1_forward_gemm; NULL keeps loc_l1_forward_rows */
+    int64_t l1_image_bytes;
+    loc_tuning tune;
 } loc_net;
+#define LOC_GEMM_MIN_ROWS 768 /* below this the in-loop-conversion kernel is faster than image + GEMM */
 
 #define LOC_MAX_FWD_GRID 512
 
@@ -186,7 +198,8 @@ int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n
 int loc_l1_rows_supported(int Hp, int pieces);
 int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                         const float* scale_shift, const float* w1s, const float* b1, float* partial,
-                        int64_t partial_floats, float* a1, int pieces, int target_blocks, void* stream);
+                        int64_t partial_floats, float* a1, int pieces, int target_blocks, const loc_tuning* tune,
+                        void* stream);
 /* The same contraction for MANY rows with the weight conversion taken out of the K loop (model.predict over all
  * samples, locator.py:414, :441; the --jacknife replicate predictions, :683-747): loc_l1_image_build streams W1S once
  * into `image` -- bf16 tiles of s_k*W1 (`pieces` per weight, 3 = exact) laid out as the GEMM's LDS tiles, plus the
@@ -214,14 +227,16 @@ int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows,
                          float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
                          float* b1, float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab,
                          int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid,
-                         const float* bn_next_stats, float* bn4_out, void* ev_after_main, void* stream);
+                         const float* bn_next_stats, float* bn4_out, void* ev_after_main, const loc_tuning* tune,
+                         void* stream);
 
 /* The main kernel of loc_l1_backward_adam alone (W1, b1 and the gamma/beta partial sums in gb_scratch); the
  * caller runs the gamma/beta update itself -- loc_train_step folds it into loc_stack_dw_adam_tail. */
 int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                               const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s, float* b1,
                               float* m_b1, float* v_b1, float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
-                              const float* lr, const int* t_base, int t_off, int grid, void* stream);
+                              const float* lr, const int* t_base, int t_off, int grid, const loc_tuning* tune,
+                              void* stream);
 
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,
@@ -256,7 +271,7 @@ int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float*
                                const float* wa, const float* ba, const float* wb, const float* bb,
                                const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
                                int slot_rows, const int32_t* rows, const float* Y, float* acts, float* adrop,
-                               float* dz, float* head_out, void* stream);
+                               float* dz, float* head_out, const loc_tuning* tune, void* stream);
 /* Inference counterpart: layers 2..L + heads for n_b rows (any n_b; a1 is [n_b][Hp]); yhat[n_b][2], optional dist[n_b]. */
 int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
                            const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
@@ -277,19 +292,6 @@ int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int
                            int alpha_tab_len, const float* lr, const int* t_base, int t_off, const loc_gb_tail* gb,
                            void* stream);
 
-/* Experimental split-K form of loc_stack_forward_backward: 4 workgroups per row group exchange partial sums
- * through tagged 8-byte granules (agent-scope relaxed atomics; no placement assumption; bounded spins). */
-/* Debug: device buffer of >= 256 int64 that the fused stack's workgroup 0 fills with wall_clock64() stamps. */
-int loc_debug_set_buffer(void* p);
-int loc_stack_split_enabled(int Hp);
-int64_t loc_stack_split_bytes(int Hp);
-int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
-                                     const float* wa, const float* ba, const float* wb, const float* bb,
-                                     const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
-                                     const int32_t* rows, const float* Y, float* acts, float* adrop, float* dz,
-                                     float* head_out, void* granules, const int* t_base, int t_off, int* err,
-                                     void* stream);
-
 /* ---- composites: what model.fit / model.predict enqueue (locator.py:367-376, :414, :441) ---- */
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).
  * n_b <= 32, or <= LOC_MAX_BATCH when net->slot_rows = LOC_BATCH_SLOT (--batch_size > 32: needs the fused-stack
@@ -298,19 +300,10 @@ int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const 
  * bn_ready != 0: this step's [scale|shift|mean|rstd] is already in the workspace (loc_bn_epoch_stats or the
  * previous step's bn_next_stats) and the per-step statistics kernel is skipped.
  * bn_next_stats: [mean|var] of the next minibatch or NULL (see loc_l1_backward_adam).
- * Consecutive steps must alternate the parity of t_off (they do: t_off = step index + 1): the per-step
- * scratch is double-buffered on it.
  * ev_l1b0 / ev_l1b1: optional hipEvent_t recorded around the layer-1 backward kernel. */
 int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                   float* loss_out, int bn_ready, const float* bn_next_stats, int wait_side, void* ev_l1b0,
-                   void* ev_l1b1, void* stream);
-/* With net->side_stream set, each step leaves its hidden-layer dW/Adam launch running on the side stream
- * (it overlaps the next step's layer-1 forward).  wait_side != 0 makes a step wait for the previous step's
- * side work before it reads the hidden weights (pass 0 only for the first step enqueued after a
- * loc_train_join, e.g. the first step of a captured graph).  loc_train_join makes `stream` wait for the
- * last step's side work: call it before loc_predict, before copying the weights, and at the end of a
- * captured epoch. */
-int loc_train_join(const loc_net* net, void* stream);
+                   float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0, void* ev_l1b1,
+                   void* stream);
 /* The workspace's bn4 block (where loc_bn_epoch_stats must leave step 0's values). */
 float* loc_workspace_bn4(const loc_net* net);
 /* Inference forward over n rows (any n >= 0): yhat[n][2]; dist[n] if with_targets.  More than 32 rows go

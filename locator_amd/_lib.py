@@ -30,11 +30,16 @@ class Layout(C.Structure):
                                          "n_trainable", "mov_mean", "mov_var", "n_total")]
 
 
+class Tuning(C.Structure):
+    _fields_ = [("stack_helpers", C.c_int), ("stack_xcd_stride", C.c_int), ("l1b_nt_mask", C.c_int),
+                ("l1b_rows", C.c_int), ("rows_rt", C.c_int)]
+
+
 class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
-                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("side_stream", vp), ("ev_fork", vp), ("ev_join", vp), ("gran", vp), ("stack_err", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
-                ("slot_rows", C.c_int), ("predict_pieces", C.c_int)]
+                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
+                ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("tune", Tuning)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -57,18 +62,17 @@ SIGNATURES = {
                                  C.c_float, vp]),
     "loc_l1_rows_supported": (C.c_int, [C.c_int, C.c_int]),
     "loc_l1_forward_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int64, vp,
-                                      C.c_int, C.c_int, vp]),
+                                      C.c_int, C.c_int, C.POINTER(Tuning), vp]),
     "loc_l1_gemm_supported": (C.c_int, [C.c_int, C.c_int]),
     "loc_l1_image_bytes": (C.c_int64, [C.POINTER(Dims), C.c_int]),
     "loc_l1_image_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_l1_forward_gemm": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, vp, vp, C.c_int64, vp,
                                       C.c_int, vp]),
-    "loc_l1_gemm_debug_read": (C.c_int, [vp]),
     "loc_l1_backward_adam_main": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
-                                            vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+                                            vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(Tuning), vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp,
-                                       vp, vp]),
+                                       vp, C.POINTER(Tuning), vp]),
     "loc_bn_epoch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                      vp, vp, vp]),
     "loc_workspace_bn4": (vp, [C.POINTER(Net)]),
@@ -82,7 +86,7 @@ SIGNATURES = {
     "loc_stack_fused_supported": (C.c_int, [C.c_int]),
     "loc_transpose_hidden": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "loc_stack_forward_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int,
-                                             C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+                                             C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(Tuning), vp]),
     "loc_stack_forward_eval": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "loc_stack_dw_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
@@ -90,13 +94,7 @@ SIGNATURES = {
     "loc_stack_dw_adam_tail": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                          C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                          C.c_int, vp, vp, C.c_int, vp, vp]),
-    "loc_debug_set_buffer": (C.c_int, [vp]),
-    "loc_stack_split_enabled": (C.c_int, [C.c_int]),
-    "loc_stack_split_bytes": (C.c_int64, [C.c_int]),
-    "loc_stack_forward_backward_split": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
-                                                   C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
-    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
-    "loc_train_join": (C.c_int, [C.POINTER(Net), vp]),
+    "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),
     "loc_event_destroy": (C.c_int, [vp]),

@@ -65,9 +65,8 @@ static int64_t partial_floats_of(const loc_dims* d) {
     const int64_t a = (int64_t)LOC_MAX_FWD_GRID * 32 * d->Hp, b = (int64_t)LOC_ROWS_BLOCKS * LOC_ROWS_TILE * d->Hp;
     return a > b ? a : b;
 }
-// The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity: with the
-// side-stream overlap the hidden-layer dW/Adam launch of step t still reads its activations while step
-// t+1's forward is already writing the next ones.  One activation slot holds `slot` rows (32, or
+// The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity (a step's tail
+// launch may still be reading its activations when a future overlapped schedule starts the next forward).  One activation slot holds `slot` rows (32, or
 // LOC_BATCH_SLOT when --batch_size > 32); the workspace is always sized for the larger one.
 static int slot_of(const loc_net* net) { return net->slot_rows > LOC_ROWS ? LOC_BATCH_SLOT : LOC_ROWS; }
 static int64_t per_step_floats(const loc_dims* d, int slot) {
@@ -101,17 +100,9 @@ extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
 
 extern "C" float* loc_workspace_bn4(const loc_net* net) { return carve(&net->d, net->ws).bn4; }
 
-extern "C" int loc_train_join(const loc_net* net, void* stream) {
-    if (net->side_stream && net->ev_join) {
-        hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)net->ev_join, 0);
-        if (e != hipSuccess) { loc_set_error("join side stream: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    return 0;
-}
-
 extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                              float* loss_out, int bn_ready, const float* bn_next_stats, int wait_side,
-                              void* ev_l1b0, void* ev_l1b1, void* stream) {
+                              float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
+                              void* ev_l1b1, void* stream) {
     const loc_dims* d = &net->d;
     const int slot = slot_of(net);
     const int max_b = slot > LOC_ROWS ? LOC_MAX_BATCH : LOC_ROWS;
@@ -135,10 +126,9 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     if (slot > LOC_ROWS) {
         // --batch_size > 32: the step is linear in the rows (BatchNorm is the first layer, so its batch statistics
         // depend on the data only), hence the same kernels with two 32-row blocks per weight tile
-        if (!fused || (use_drop && npre == 1) || !loc_l1_rows_supported(Hp, 3) || net->side_stream ||
-            (net->gran && loc_stack_split_enabled(Hp))) {
-            loc_set_error("loc_train_step: --batch_size > 32 needs width 64/128/256 (after padding), nlayers >= 4 "
-                          "when dropout is on, and none of the experimental stream / split-K modes");
+        if (!fused || (use_drop && npre == 1) || !loc_l1_rows_supported(Hp, 3)) {
+            loc_set_error("loc_train_step: --batch_size > 32 needs width 64/128/256 (after padding) and nlayers >= 4 "
+                          "when dropout is on");
             return -1;
         }
         if (!bn_ready && n_b > LOC_ROWS) {
@@ -152,68 +142,34 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     if (n_b > LOC_ROWS) {
         // large-M forward, exact fp32 products (3 bf16 pieces); fills one whole 128-row activation slot
         TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
-                                w.partial_floats, act(1), 3, 0, stream));
+                                w.partial_floats, act(1), 3, 0, &net->tune, stream));
     } else {
         const bool dr = use_drop && npre == 1;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                            net->l1_fwd_grid, act(1), dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
     }
     if (fused) {
-        // fused row-parallel hidden stack: 2 launches instead of 2(L-1)+2
-        const bool fork = net->side_stream && net->ev_fork && net->ev_join;
-        // the previous step's hidden-layer dW/Adam launch (side stream) must be done before the hidden
-        // weights are read again
-        if (fork && wait_side) TRY(loc_train_join(net, stream));
-        if (net->gran && net->stack_err && loc_stack_split_enabled(Hp)) {
-            TRY(loc_stack_forward_backward_split(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
-                                                 P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre,
-                                                 n_b, rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, net->gran,
-                                                 net->t_base, t_off, net->stack_err, stream));
-        } else {
-            TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba,
-                                           P + lay.wb, P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b,
-                                           slot, rows, net->Y, w.acts, w.adrop, w.dz, w.head_out, stream));
-        }
-        if (!fork) {
-            // stack -> layer-1 backward -> ONE tail launch for everything that reduces over the batch rows:
-            // hidden-layer dW/db + Adam, heads, batch loss, and the BatchNorm gamma/beta update (plus the next
-            // step's scale/shift).  The hidden tail only needs what the stack kernel left in scratch, so it can
-            // sit after the layer-1 backward and share a launch with the gamma/beta tail.
-            if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
-            TRY(loc_l1_backward_adam_main(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
-                                          V + lay.w1, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
-                                          net->t_base, t_off, net->l1_bwd_grid, stream));
-            if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
-            loc_gb_tail gb;
-            gb.K = d->K; gb.Kp = d->Kp; gb.gbs = w.gbs;
-            gb.gamma = P + lay.gamma; gb.beta = P + lay.beta;
-            gb.m_gamma = M + lay.gamma; gb.v_gamma = V + lay.gamma;
-            gb.m_beta = M + lay.beta; gb.v_beta = V + lay.beta;
-            gb.next_stats = bn_next_stats; gb.bn4 = w.bn4;
-            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
-                                       net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
-                                       net->lr, net->t_base, t_off, &gb, stream));
-            return 0;
-        }
+        // fused row-parallel hidden stack -> layer-1 backward -> ONE tail launch for everything that reduces over the
+        // batch rows: hidden-layer dW/db + Adam, heads, batch loss, and the BatchNorm gamma/beta update (plus the next
+        // step's scale/shift).  The hidden tail only needs what the stack kernel left in scratch, so it can sit after
+        // the layer-1 backward and share a launch with the gamma/beta tail.
+        TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
+                                       P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, slot, rows, net->Y,
+                                       w.acts, w.adrop, w.dz, w.head_out, &net->tune, stream));
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
-        TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
-                                 V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta,
-                                 V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
-                                 net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, stream));
-        if (fork) {
-            // The hidden-layer dW/Adam launch needs only what the stack kernel left in this step's scratch
-            // parity, and nothing reads its results before the NEXT step's stack kernel.  Forked here, after
-            // the layer-1 backward (which saturates HBM and owns every CU), it overlaps the gamma/beta kernel
-            // and the next step's layer-1 forward + reduce instead of sitting on the critical path.
-            hipError_t e = hipEventRecord((hipEvent_t)net->ev_fork, (hipStream_t)stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)net->side_stream, (hipEvent_t)net->ev_fork, 0);
-            if (e != hipSuccess) { loc_set_error("fork to side stream: %s", hipGetErrorString(e)); return (int)e; }
-            TRY(loc_stack_dw_adam(Hp, L, npre, n_b, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
-                                  net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
-                                  net->lr, net->t_base, t_off, net->side_stream));
-            e = hipEventRecord((hipEvent_t)net->ev_join, (hipStream_t)net->side_stream);
-            if (e != hipSuccess) { loc_set_error("side stream record: %s", hipGetErrorString(e)); return (int)e; }
-        }
+        TRY(loc_l1_backward_adam_main(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
+                                      V + lay.w1, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
+                                      net->t_base, t_off, net->l1_bwd_grid, &net->tune, stream));
+        if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+        loc_gb_tail gb;
+        gb.K = d->K; gb.Kp = d->Kp; gb.gbs = w.gbs;
+        gb.gamma = P + lay.gamma; gb.beta = P + lay.beta;
+        gb.m_gamma = M + lay.gamma; gb.v_gamma = V + lay.gamma;
+        gb.m_beta = M + lay.beta; gb.v_beta = V + lay.beta;
+        gb.next_stats = bn_next_stats; gb.bn4 = w.bn4;
+        TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M, V,
+                                   net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl, net->lr,
+                                   net->t_base, t_off, &gb, stream));
         return 0;
     }
     for (int l = 2; l <= L; ++l) {
@@ -244,7 +200,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
                              P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
                              P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
-                             net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, stream));
+                             net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, &net->tune, stream));
     return 0;
 }
 
@@ -262,11 +218,19 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
                                  w.bn4, stream));
     const int pieces = net->predict_pieces == 0 ? 3 : net->predict_pieces;
     if (n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) {
-        // large-M layer 1 on the bf16 matrix pipe, then ONE row-parallel stack launch per chunk
+        // large-M layer 1 on the bf16 matrix pipe, then ONE row-parallel stack launch per chunk.  Many rows: the
+        // weights are converted once into the caller's image buffer and every chunk runs the pure-MFMA GEMM
+        const bool gemm = n >= LOC_GEMM_MIN_ROWS && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
+                          net->l1_image_bytes >= loc_l1_image_bytes(d, pieces);
+        if (gemm) TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
+            if (gemm)
+                TRY(loc_l1_forward_gemm(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, pieces, P + lay.b1,
+                                        w.partial, w.partial_floats, w.a1_rows, 0, stream));
+            else
             TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows + c0, nc, d, w.bn4, P + lay.w1, P + lay.b1,
-                                    w.partial, w.partial_floats, w.a1_rows, pieces, 0, stream));
+                                    w.partial, w.partial_floats, w.a1_rows, pieces, 0, &net->tune, stream));
             TRY(loc_stack_forward_eval(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
                                        P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
                                        with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,

@@ -109,6 +109,27 @@ __host__ __device__ inline int64_t w1s_index(int h, int k, int nht) {
 
 // host-side error plumbing (api.hip)
 void loc_set_error(const char* fmt, ...);
+
+// Raises a kernel's dynamic-LDS limit.  The limit is an attribute of the function PER DEVICE, so the "largest value
+// set so far" is remembered per (call site = kernel instantiation, device); the call is idempotent, which makes the
+// unsynchronised cache benign.  FUNC may hold template commas: wrap it in parentheses.
+#define LOC_MAX_DEVICES 64
+#define LOC_ENSURE_LDS(FUNC, BYTES)                                                                          \
+    do {                                                                                                     \
+        static size_t set__[LOC_MAX_DEVICES] = {};                                                           \
+        int dev__ = 0;                                                                                       \
+        (void)hipGetDevice(&dev__);                                                                          \
+        dev__ = dev__ < 0 ? 0 : dev__ % LOC_MAX_DEVICES;                                                     \
+        if ((size_t)(BYTES) > set__[dev__]) {                                                                \
+            hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(FUNC),                        \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));  \
+            if (e__ != hipSuccess) {                                                                         \
+                loc_set_error("hipFuncSetAttribute(%zu): %s", (size_t)(BYTES), hipGetErrorString(e__));     \
+                return (int)e__;                                                                             \
+            }                                                                                                \
+            set__[dev__] = (size_t)(BYTES);                                                                  \
+        }                                                                                                    \
+    } while (0)
 #define LOC_CHECK_LAUNCH()                                              \
     do {                                                                \
         hipError_t e__ = hipGetLastError();                             \

@@ -774,8 +774,7 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
     const size_t lds = 2 * (size_t)(d->Hp + 32) * LP * sizeof(float);
 #define LAUNCH_FWD(N)                                                                                      \
     {                                                                                                      \
-        static size_t lds_set = 0;                                               \
-        if (lds > lds_set) { int rc = set_max_lds(l1_fwd_partial_kernel<N>, lds); if (rc) return rc; lds_set = lds; }                                                                                 \
+        LOC_ENSURE_LDS((l1_fwd_partial_kernel<N>), lds);                                                   \
         hipLaunchKernelGGL(l1_fwd_partial_kernel<N>, dim3(grid), dim3(512), lds, (hipStream_t)stream, X,   \
                            x_pitch, rows, n_b, d->Kp, scale_shift, w1s, partial);                          \
     }
@@ -801,7 +800,8 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
                                          const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
                                          float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
                                          float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
-                                         const float* lr, const int* t_base, int t_off, int grid, void* stream) {
+                                         const float* lr, const int* t_base, int t_off, int grid,
+                                         const loc_tuning* tune, void* stream) {
     if (n_b < 1 || n_b > LOC_MAX_BATCH) {
         loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..%d", n_b, LOC_MAX_BATCH);
         return -1;
@@ -815,12 +815,10 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     const int rb = (n_b + LOC_ROWS - 1) / LOC_ROWS;
     const size_t lds = rb == 1 ? ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float)
                                : ((size_t)d->Hp * (32 * rb + 4) + d->Hp + 32 * rb) * sizeof(float);
-    static int rows1 = -1;      // LOC_L1B_ROWS=1: the bf16x3 row-block kernel also for <= 32 rows (measurement knob)
-    if (rows1 < 0) { const char* e = getenv("LOC_L1B_ROWS"); rows1 = e ? atoi(e) : 0; }
-    if (rb == 1 && rows1 && nht == 8) {
+    // tune->l1b_rows = 1: the bf16x3 row-block kernel also for <= 32 rows (measurement / parity switch)
+    if (rb == 1 && tune && tune->l1b_rows == 1 && nht == 8) {
         const size_t lds = ((size_t)d->Hp * 36 + d->Hp + 32) * sizeof(float);
-        static size_t lds_set = 0;
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_rows_kernel<8, 13, 1>, lds); if (rc) return rc; lds_set = lds; }
+        LOC_ENSURE_LDS((l1_bwd_adam_rows_kernel<8, 13, 1>), lds);
         hipLaunchKernelGGL((l1_bwd_adam_rows_kernel<8, 13, 1>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X,
                            x_pitch, rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);
@@ -832,8 +830,7 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
         // RB = 2 keeps two workgroups per CU (66 KB of dz each at width 256); RB = 3, 4 run one per CU.
 #define LAUNCH_BWD_RB(N, R)                                                                                    \
     {                                                                                                          \
-        static size_t lds_set = 0;                                                                             \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_rows_kernel<N, 13, R>, lds); if (rc) return rc; lds_set = lds; } \
+        LOC_ENSURE_LDS((l1_bwd_adam_rows_kernel<N, 13, R>), lds);                                              \
         hipLaunchKernelGGL((l1_bwd_adam_rows_kernel<N, 13, R>), dim3(R > 2 ? (n_active + 7) / 8 : grid),         \
                            dim3(R > 2 ? 512 : 256), lds, (hipStream_t)stream, X, x_pitch,                      \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
@@ -858,19 +855,17 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     }
 #define LAUNCH_BWD(N)                                                                                          \
     {                                                                                                          \
-        static size_t lds_set = 0;                                                                             \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<N>, lds); if (rc) return rc; lds_set = lds; } \
+        LOC_ENSURE_LDS((l1_bwd_adam_kernel<N>), lds);                                                          \
         hipLaunchKernelGGL(l1_bwd_adam_kernel<N>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
     }
-    // LOC_L1B_NT = 0 | 9 | 13 | 15 overrides the cache-policy mask NTM for width 256 (measurement knob)
-    static int ntm = -2;
-    if (ntm == -2) { const char* e = getenv("LOC_L1B_NT"); ntm = e ? atoi(e) : -1; }
+    // tune->l1b_nt_mask = 9 | 13 | 15 (or -1 for "nothing non-temporal") overrides the cache-policy mask NTM for
+    // width 256 (measurement switch); 0 = the kernel's default
+    const int ntm = !tune || tune->l1b_nt_mask == 0 ? -1 : (tune->l1b_nt_mask < 0 ? 0 : tune->l1b_nt_mask);
 #define LAUNCH_BWD_NT(M)                                                                                       \
     {                                                                                                          \
-        static size_t lds_set = 0;                                                                             \
-        if (lds > lds_set) { int rc = set_max_lds(l1_bwd_adam_kernel<8, M>, lds); if (rc) return rc; lds_set = lds; } \
+        LOC_ENSURE_LDS((l1_bwd_adam_kernel<8, M>), lds);                                                       \
         hipLaunchKernelGGL((l1_bwd_adam_kernel<8, M>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
                            alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
@@ -894,9 +889,9 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                                     float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
                                     float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
                                     const int* t_base, int t_off, int grid, const float* bn_next_stats,
-                                    float* bn4_out, void* ev_after_main, void* stream) {
+                                    float* bn4_out, void* ev_after_main, const loc_tuning* tune, void* stream) {
     int rc = loc_l1_backward_adam_main(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, b1, m_b1, v_b1, gb_scratch,
-                                       alpha_tab, alpha_tab_len, lr, t_base, t_off, grid, stream);
+                                       alpha_tab, alpha_tab_len, lr, t_base, t_off, grid, tune, stream);
     if (rc) return rc;
     if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,

@@ -31,8 +31,6 @@
 // conflicts 1/3 of LDS cycles before the store-order fix in conv_w — the conversion, not the matrix pipe,
 // is what a later round has to shrink (e.g. convert once per call into an HBM bf16 image when the same
 // weights serve many row tiles, as --jacknife does).
-#include <stdlib.h>
-
 #include "common.h"
 
 
@@ -287,17 +285,6 @@ __global__ __launch_bounds__(NT) void l1_rows_partial_kernel(const uint8_t* __re
     }
 }
 
-template <typename F>
-static int set_max_lds_rows(F* func, size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(func),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-        loc_set_error("hipFuncSetAttribute(%zu): %s", bytes, hipGetErrorString(e));
-        return (int)e;
-    }
-    return 0;
-}
-
 static size_t rows_lds_bytes(int Hp, int pieces, int rt) {
     return 2 * ((size_t)rt * 32 * 64 + (size_t)pieces * Hp * 64) + (size_t)Hp * 4;
 }
@@ -315,8 +302,7 @@ int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const 
 
 #define ROWS_CASE(N, PP, RR, TT)                                                                                 \
     {                                                                                                            \
-        static size_t lds_set = 0;                                                                               \
-        if (lds > lds_set) { int rc = set_max_lds_rows(l1_rows_partial_kernel<N, PP, RR, TT>, lds); if (rc) return rc; lds_set = lds; } \
+        LOC_ENSURE_LDS((l1_rows_partial_kernel<N, PP, RR, TT>), lds);                                            \
         hipLaunchKernelGGL((l1_rows_partial_kernel<N, PP, RR, TT>), dim3(n_mt * G), dim3(TT), lds,               \
                            (hipStream_t)stream, X, x_pitch, rows, n, d->Kp, scale_shift, w1s, partial, G, Mp);   \
     }
@@ -338,15 +324,10 @@ int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const 
         default: loc_set_error("loc_l1_forward_rows: width %d unsupported", 32 * nht); return -1;                 \
     }
 
-static int rows_tile_override() {      // LOC_ROWS_RT=8: 256-row tiles (measurement knob)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LOC_ROWS_RT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 extern "C" int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                                    const float* scale_shift, const float* w1s, const float* b1, float* partial,
-                                   int64_t partial_floats, float* a1, int pieces, int target_blocks, void* stream) {
+                                   int64_t partial_floats, float* a1, int pieces, int target_blocks,
+                                   const loc_tuning* tune, void* stream) {
     if (n < 1) { loc_set_error("loc_l1_forward_rows: n=%d", n); return -1; }
     if (!loc_l1_rows_supported(d->Hp, pieces)) {
         loc_set_error("loc_l1_forward_rows: width %d with %d pieces does not fit the LDS", d->Hp, pieces);
@@ -354,12 +335,12 @@ extern "C" int loc_l1_forward_rows(const uint8_t* X, int64_t x_pitch, const int3
     }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (target_blocks < 1) target_blocks = 256;
-    // Default: 128-row tiles, 8 waves.  LOC_ROWS_RT=8 selects the 256-row / 4-wave tile (half the conversion
+    // Default: 128-row tiles, 8 waves.  tune->rows_rt = 8 selects the 256-row / 4-wave tile (half the conversion
     // and LDS operand traffic per flop, accumulators in AGPRs; needs ceil(n/128) even because a1 is written in
     // whole tiles of LOC_ROWS_TILE = 128 rows).  Measured equal within noise on 1000 x 100k x 256
     // (203-209 vs 208-219 us), so it stays a measurement knob.
     const int n128 = (n + LOC_ROWS_TILE - 1) / LOC_ROWS_TILE;
-    const bool big = rows_tile_override() == 8 && (n128 % 2) == 0 && rows_big_ok(d->Hp, pieces);
+    const bool big = tune && tune->rows_rt == 8 && (n128 % 2) == 0 && rows_big_ok(d->Hp, pieces);
     const int rmt = big ? 256 : 128;
     const int n_mt = (n + rmt - 1) / rmt, Mp = n_mt * rmt;
     int G = target_blocks / n_mt;

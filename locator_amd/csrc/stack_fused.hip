@@ -21,25 +21,16 @@
 // barrier has to provide ("memory" keeps the compiler from moving accesses across it).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NHT, int R, bool TRAIN, bool DBG>
+template <int NHT, int R, bool TRAIN>
 __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     const float* __restrict__ a1_in, const float* __restrict__ Wh, const float* __restrict__ WhT,
     const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba,
     const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
     int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
-    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work,
-    long long* __restrict__ dbg, int slot_rows) {
+    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work, int slot_rows) {
     constexpr int Hp = NHT * 32;
     constexpr int C4 = Hp / 4;               // float4 columns per weight row
-    // DBG instantiation only (tools/stack_phase_timing.py): per-phase wall_clock64 stamps from workgroup 0.
-    // Kept out of the production instantiation: the stamps cost >150 spilled registers.
-    int dbg_n = 0;
-    auto stamp = [&]() {
-        if constexpr (DBG) {
-            if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dbg[dbg_n++] = (long long)wall_clock64();
-        }
-    };
     constexpr int KG = SF_THREADS / C4;      // k-groups
     constexpr int KPG = Hp / KG;             // k per group
     static_assert(SF_THREADS % C4 == 0 && Hp % KG == 0 && KPG >= 1, "unsupported width for the fused stack");
@@ -175,11 +166,8 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
                 if (dr) e_keep[o] = mask[(int64_t)(r0 + i / Hp) * Hp + i % Hp] ? keep_scale : 0.f;
             }
         }
-        stamp();
         contract(wseq(l - 2), wseq(l - 1));
-        stamp();
         lds_barrier();
-        stamp();
         float* aout = acts + (int64_t)(l - 1) * blk;
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
@@ -197,10 +185,8 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
                 act[r][n] = nx;
             }
         }
-        stamp();
         lds_barrier();
     }
-    stamp();
 
     // ---------------- heads + loss (per row)
     {
@@ -510,35 +496,23 @@ extern "C" int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_h
 
 constexpr int SF_R = 2;   // batch rows per workgroup -> 16 workgroups per 32-row block
 
-static long long* g_sf_dbg = nullptr;
-extern "C" int loc_debug_set_buffer(void* p) { g_sf_dbg = (long long*)p; return 0; }
-static bool sf_probe_bwd_w() { static int v = -1; if (v < 0) { const char* e = getenv("LOC_DEBUG_BWD_USE_W"); v = e && atoi(e) ? 1 : 0; } return v == 1; }
-
-static int sf_helpers() {          // L2 warm-up helper workgroups (only meaningful with the XCD placement hint)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LOC_STACK_HELPERS");
-        v = e ? atoi(e) : 12;         // measured: 0 -> 78.6 us, 4 -> 63, 8 -> 51.7, 12 -> 51.0, 32 -> 55 (width 256)
-        if (v < 0) v = 0;
-    }
-    return v;
+// L2 warm-up helper workgroups and XCD placement stride of the fused stack: speed hints (loc_tuning), defaults
+// measured at width 256: helpers 0 -> 78.6 us, 4 -> 63, 8 -> 51.7, 12 -> 51.0, 32 -> 55
+static int sf_helpers(const loc_tuning* tune) {
+    if (!tune || tune->stack_helpers == 0) return 12;
+    return tune->stack_helpers < 0 ? 0 : tune->stack_helpers;
 }
-
-static int sf_xcd_stride() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LOC_STACK_XCD_STRIDE");
-        v = e ? atoi(e) : 8;
-        if (v < 1) v = 1;
-    }
-    return v;
+static int sf_xcd_stride(const loc_tuning* tune) {
+    const int v = tune ? tune->stack_xcd_stride : 0;
+    return v == 1 || v == 2 || v == 4 || v == 8 ? v : 8;
 }
 
 extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float* WhT, const float* bh,
                                           const float* wa, const float* ba, const float* wb, const float* bb,
                                           const uint8_t* mask, float keep_scale, int Hp, int L, int n_pre, int n_b,
                                           int slot_rows, const int32_t* rows, const float* Y, float* acts,
-                                          float* adrop, float* dz, float* head_out, void* stream) {
+                                          float* adrop, float* dz, float* head_out, const loc_tuning* tune,
+                                          void* stream) {
     if (n_b < 1 || n_b > slot_rows || slot_rows % 32) {
         loc_set_error("loc_stack_forward_backward: n_b=%d, slot_rows=%d", n_b, slot_rows);
         return -1;
@@ -546,25 +520,17 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
     // every row of the row blocks in use is carried (rows >= n_b get a zero loss gradient), so the tail and the
     // layer-1 backward can contract whole 32-row blocks
     const int nblk = (n_b + 31) / 32 * (32 / SF_R);
-    int xs = sf_xcd_stride();
-    int nh = xs > 1 ? sf_helpers() : 0;
+    int xs = sf_xcd_stride(tune);
+    int nh = xs > 1 ? sf_helpers(tune) : 0;
     while (xs > 1 && (nblk + nh + 8 / xs - 1) / (8 / xs) > 32) {     // more row groups than one XCD holds
         xs /= 2;
         nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);
     }
     if (xs == 1) nh = 0;
-    if (sf_probe_bwd_w()) WhT = Wh;          // timing probe only: wrong numerics
 #define LAUNCH(N)                                                                                                  \
-    if (g_sf_dbg)                                                                                                  \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, true>), dim3((nblk + nh) * xs),                      \
-                           dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
-                           keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
-                           (float*)nullptr, xs, nblk, g_sf_dbg, slot_rows);                                        \
-    else                                                                                                           \
-        hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true, false>), dim3((nblk + nh) * xs),                     \
-                           dim3(SF_THREADS), 0, (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask,     \
-                           keep_scale, L, n_pre, n_b, rows, Y, acts, adrop, dz, head_out, (float*)nullptr,         \
-                           (float*)nullptr, xs, nblk, (long long*)nullptr, slot_rows);
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,           \
+                       (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,  \
+                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs, nblk, slot_rows);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -574,21 +540,22 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
 extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa,
                                       const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
                                       const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+    const loc_tuning* tune = nullptr;
     const int nblk = (n_b + SF_R - 1) / SF_R;
     // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups
     // than one XCD holds, spread them over 2, 4 or all 8 XCDs (stride 4, 2, 1) instead of running in rounds.
-    int xs = sf_xcd_stride();
-    int nh = xs > 1 ? sf_helpers() : 0;
+    int xs = sf_xcd_stride(tune);
+    int nh = xs > 1 ? sf_helpers(tune) : 0;
     while (xs > 1 && (nblk + nh + 8 / xs - 1) / (8 / xs) > 32) {
         xs /= 2;
         nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);      // the same number of helpers on every XCD in use
     }
     if (xs == 1) nh = 0;
 #define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
+    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
                        (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
-                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, (long long*)nullptr, 32);
+                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, 32);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
@@ -637,314 +604,3 @@ extern "C" int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop
                                   off_wh, off_bh, off_wa, off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len,
                                   lr, t_base, t_off, nullptr, stream);
 }
-
-// =============================================================================================
-// Split-K variant of the fused stack (experimental; LOC_STACK_SPLIT=4).
-//
-// A single workgroup can only pull ~65-100 GB/s through its L1, so streaming a whole 256 KB kernel
-// per layer pass costs ~4 us however deep the prefetch.  Here every row group is served by S
-// workgroups; workgroup (g, s) contracts only rows [s*Hp/S, (s+1)*Hp/S) of each layer's kernel (1/S of
-// the bytes) and the S partial results (R x Hp floats each) are exchanged once per pass through the
-// tagged-granule hand-off of /opt/skills/guides/cdna_hip_programming.md §6 G16 (R2): every value
-// travels as ONE aligned 8-byte {tag, value} word written with a relaxed agent-scope (sc1) store and
-// read with relaxed agent-scope loads until the tag matches — the data is the flag, no fence, no
-// placement assumption.  tag = 64 * (Adam step) + pass + 1 is unique per launch and pass, so the
-// buffers are never re-initialised; slots are double-buffered by pass parity, which is enough because a
-// workgroup can only run one pass ahead of its slowest peer.  All S workgroups of a group then hold the
-// same full result (summed in the same order) and run the cheap epilogue redundantly.  Spins are
-// bounded; on a timeout err[0] is set and the launch still terminates.
-// =============================================================================================
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-
-template <int NHT, int R, int S>
-__global__ __launch_bounds__(SF_THREADS) void stack_fused_split_kernel(
-    const float* __restrict__ a1_in, const float* __restrict__ Wh, const float* __restrict__ WhT,
-    const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba,
-    const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
-    int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
-    float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
-    unsigned long long* __restrict__ gran, const int* __restrict__ t_base, int t_off, int* __restrict__ err,
-    int xcd_stride) {
-    constexpr int Hp = NHT * 32;
-    constexpr int C4 = Hp / 4;
-    constexpr int KG = SF_THREADS / C4;          // k-groups inside the workgroup
-    constexpr int KS = Hp / S;                   // kernel rows of this workgroup's slice
-    constexpr int KPG = KS / KG;                 // rows per k-group
-    constexpr int NO = (R * Hp + SF_THREADS - 1) / SF_THREADS;
-    static_assert(KS % KG == 0 && KPG >= 1 && KPG <= 32, "unsupported split");
-    __shared__ __attribute__((aligned(16))) float act[R][Hp];
-    __shared__ __attribute__((aligned(16))) float part[KG][R][Hp];
-    __shared__ float hs[R][8];
-    // every slice keeps its own copy of the group's ELU outputs (layers 2..L) for the backward ELU':
-    // only slice 0 writes them to global, and a peer's plain store must not be read inside the launch
-    extern __shared__ __attribute__((aligned(16))) float alds[];      // [L + 1][R][Hp], slot l = layer l
-
-    if (xcd_stride > 1 && (blockIdx.x % xcd_stride) != 0) return;
-    const int wg = xcd_stride > 1 ? blockIdx.x / xcd_stride : blockIdx.x;
-    const int g = wg / S, s = wg % S;
-    const int t = threadIdx.x, c4 = t % C4, kq = t / C4;
-    const int r0 = g * R;
-    const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
-    const unsigned tag_base = (unsigned)(t_base[0] + t_off) * 64u;
-    constexpr int SLOT = R * Hp;                 // granules per (parity, group, slice)
-    gu64* gbase = (gu64*)gran;
-
-    for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = a1_in[(int64_t)(r0 + i / Hp) * Hp + i % Hp];
-    __syncthreads();
-
-    f32x4 buf[KPG];
-    auto load_slice = [&](const float* __restrict__ Wsrc) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(Wsrc) + (int64_t)(s * KS + kq * KPG) * C4 + c4;
-#pragma unroll
-        for (int j = 0; j < KPG; ++j) buf[j] = wp[(int64_t)j * C4];
-    };
-    const int n_pass = 2 * (L - 1);
-    auto wseq = [&](int p) -> const float* {
-        if (p >= n_pass) return Wh;
-        return p < L - 1 ? Wh + (int64_t)p * HH : WhT + (int64_t)(2 * (L - 1) - 1 - p) * HH;
-    };
-    // contraction over this slice, partial over k-groups into LDS, then prefetch the next pass's slice
-    auto contract = [&](const float* __restrict__ Wnext) {
-        f32x4 acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < KPG; ++j) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float a = act[r][s * KS + kq * KPG + j];
-                acc[r][0] = fmaf(a, buf[j][0], acc[r][0]);
-                acc[r][1] = fmaf(a, buf[j][1], acc[r][1]);
-                acc[r][2] = fmaf(a, buf[j][2], acc[r][2]);
-                acc[r][3] = fmaf(a, buf[j][3], acc[r][3]);
-            }
-        }
-        load_slice(Wnext);
-#pragma unroll
-        for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(&part[kq][r][4 * c4]) = acc[r];
-    };
-    // exchange: publish this workgroup's partial for element i, gather the S partials in slice order
-    auto exchange = [&](int pass, int i) -> float {
-        float mine = 0.f;
-#pragma unroll
-        for (int q = 0; q < KG; ++q) mine += part[q][i / Hp][i % Hp];
-        const unsigned tag = tag_base + (unsigned)pass + 1u;
-        gu64* slot = gbase + ((int64_t)((pass & 1) * 16 + g) * S) * SLOT;
-        __hip_atomic_store(slot + (int64_t)s * SLOT + i, ((unsigned long long)tag << 32) | __float_as_uint(mine),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // poll every peer's granule at once (one visibility latency, not S-1 of them)
-        unsigned long long xv[S];
-        unsigned spins = 0;
-        bool ok;
-        do {
-            ok = true;
-#pragma unroll
-            for (int q = 0; q < S; ++q) {
-                xv[q] = __hip_atomic_load(slot + (int64_t)q * SLOT + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int q = 0; q < S; ++q) ok &= (q == s) | ((unsigned)(xv[q] >> 32) == tag);
-            if (!ok) __builtin_amdgcn_s_sleep(4);       // back off: hot polling by 512 lanes starves the publishers
-        } while (!ok && ++spins < (1u << 20));
-        if (!ok) err[0] = 1;
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < S; ++q) sum += (q == s) ? mine : __uint_as_float((unsigned)xv[q]);   // fixed slice order
-        return sum;
-    };
-
-    float h_wa0 = 0.f, h_wa1 = 0.f;
-    if (t < Hp) { h_wa0 = wa[2 * t]; h_wa1 = wa[2 * t + 1]; }
-    float h_ba0 = 0.f, h_ba1 = 0.f, h_w00 = 0.f, h_w01 = 0.f, h_w10 = 0.f, h_w11 = 0.f, h_bb0 = 0.f, h_bb1 = 0.f;
-    float h_y0 = 0.f, h_y1 = 0.f;
-    if (t < R) {
-        h_ba0 = ba[0]; h_ba1 = ba[1]; h_w00 = wb[0]; h_w01 = wb[1]; h_w10 = wb[2]; h_w11 = wb[3];
-        h_bb0 = bb[0]; h_bb1 = bb[1];
-        if (r0 + t < n_b) { h_y0 = Y[(int64_t)rows[r0 + t] * 2]; h_y1 = Y[(int64_t)rows[r0 + t] * 2 + 1]; }
-    }
-    load_slice(wseq(0));
-
-    // ---------------- forward
-    for (int l = 2; l <= L; ++l) {
-        const int pass = l - 2;
-        const float* bias = bh + (int64_t)(l - 2) * Hp;
-        const bool dr = mask != nullptr && l == n_pre;
-        float e_bias[NO], e_keep[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            e_bias[o] = 0.f; e_keep[o] = 1.f;
-            if (i < R * Hp) {
-                e_bias[o] = bias[i % Hp];
-                if (dr) e_keep[o] = mask[(int64_t)(r0 + i / Hp) * Hp + i % Hp] ? keep_scale : 0.f;
-            }
-        }
-        contract(wseq(pass + 1));
-        lds_barrier();
-        float* aout = acts + (int64_t)(l - 1) * blk;
-        float nxv[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            nxv[o] = 0.f;
-            if (i < R * Hp) {
-                const float a = elu_f(exchange(pass, i) + e_bias[o]);
-                const int64_t gi = (int64_t)(r0 + i / Hp) * Hp + i % Hp;
-                float nx = a;
-                if (dr) nx = a * e_keep[o];
-                if (s == 0) {
-                    aout[gi] = a;
-                    if (dr) adrop[gi] = nx;
-                }
-                alds[(l * R + i / Hp) * Hp + i % Hp] = a;
-                nxv[o] = nx;
-            }
-        }
-        lds_barrier();                     // everyone is done reading part / act
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            if (i < R * Hp) act[i / Hp][i % Hp] = nxv[o];
-        }
-        lds_barrier();
-    }
-
-    // ---------------- heads + loss (every workgroup of the group computes them identically)
-    {
-        float p0[R], p1[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
-        if (t < Hp) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) { p0[r] = act[r][t] * h_wa0; p1[r] = act[r][t] * h_wa1; }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { p0[r] += __shfl_xor(p0[r], o); p1[r] += __shfl_xor(p1[r], o); }
-            if ((t & 63) == 0) { part[0][r][2 * (t >> 6)] = p0[r]; part[0][r][2 * (t >> 6) + 1] = p1[r]; }
-        }
-        lds_barrier();
-        if (t < R) {
-            const int r = t, b = r0 + r;
-            float y10 = h_ba0, y11 = h_ba1;
-            for (int w = 0; w < SF_THREADS / 64; ++w) { y10 += part[0][r][2 * w]; y11 += part[0][r][2 * w + 1]; }
-            const float y20 = y10 * h_w00 + y11 * h_w10 + h_bb0;
-            const float y21 = y10 * h_w01 + y11 * h_w11 + h_bb1;
-            float d = 0.f, g0 = 0.f, g1 = 0.f;
-            if (b < n_b) {
-                const float e0 = y20 - h_y0, e1 = y21 - h_y1;
-                d = sqrtf(fmaxf(e0 * e0 + e1 * e1, 0.f));
-                if (d > 0.f) { g0 = e0 / d / (float)n_b; g1 = e1 / d / (float)n_b; }
-            }
-            const float dy10 = g0 * h_w00 + g1 * h_w01, dy11 = g0 * h_w10 + g1 * h_w11;
-            hs[r][0] = dy10; hs[r][1] = dy11;
-            if (s == 0) {
-                float* ho = head_out + 8 * b;
-                ho[0] = d; ho[1] = dy10; ho[2] = dy11; ho[3] = y10; ho[4] = y11; ho[5] = g0; ho[6] = g1; ho[7] = 0.f;
-            }
-        }
-        lds_barrier();
-    }
-    {   // dz_L
-        float* dzo = dz + (int64_t)(L - 1) * blk;
-        float nxv[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            nxv[o] = 0.f;
-            if (i < R * Hp) {
-                const int r = i / Hp, k = i % Hp;
-                const float v = (hs[r][0] * wa[2 * k] + hs[r][1] * wa[2 * k + 1]) * elu_grad_from_act(act[r][k]);
-                if (s == 0) dzo[(int64_t)(r0 + r) * Hp + k] = v;
-                nxv[o] = v;
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            if (i < R * Hp) act[i / Hp][i % Hp] = nxv[o];
-        }
-        lds_barrier();
-    }
-    // ---------------- backward
-    for (int l = L; l >= 2; --l) {
-        const int pass = (L - 1) + (L - l);
-        const bool dr = mask != nullptr && l - 1 == n_pre;
-        float e_g[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            e_g[o] = 0.f;
-            if (i < R * Hp) {
-                const int64_t gi = (int64_t)(r0 + i / Hp) * Hp + i % Hp;
-                float keep = 1.f;
-                if (dr) keep = mask[gi] ? keep_scale : 0.f;
-                // ELU output of layer l-1: layer 1's comes from the previous launch (global), deeper ones
-                // from this workgroup's own LDS copy
-                const float ap = (l - 1 == 1) ? acts[gi] : alds[((l - 1) * R + i / Hp) * Hp + i % Hp];
-                e_g[o] = keep * elu_grad_from_act(ap);
-            }
-        }
-        contract(wseq(pass + 1));
-        lds_barrier();
-        float* dzo = dz + (int64_t)(l - 2) * blk;
-        float nxv[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            nxv[o] = 0.f;
-            if (i < R * Hp) {
-                const float v = exchange(pass, i) * e_g[o];
-                if (s == 0) dzo[(int64_t)(r0 + i / Hp) * Hp + i % Hp] = v;
-                nxv[o] = v;
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int i = t + SF_THREADS * o;
-            if (i < R * Hp) act[i / Hp][i % Hp] = nxv[o];
-        }
-        lds_barrier();
-    }
-}
-
-static int sf_split() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("LOC_STACK_SPLIT");
-        v = e ? atoi(e) : 0;
-        if (v != 4) v = 0;
-    }
-    return v;
-}
-
-// granule buffer: 2 parities x 16 row groups x S slices x (R*Hp) granules of 8 bytes
-extern "C" int64_t loc_stack_split_bytes(int Hp) { return 2LL * 16 * 4 * SF_R * (int64_t)Hp * 8; }
-
-extern "C" int loc_stack_forward_backward_split(const float* a1_in, const float* Wh, const float* WhT,
-                                                const float* bh, const float* wa, const float* ba, const float* wb,
-                                                const float* bb, const uint8_t* mask, float keep_scale, int Hp, int L,
-                                                int n_pre, int n_b, const int32_t* rows, const float* Y, float* acts,
-                                                float* adrop, float* dz, float* head_out, void* granules,
-                                                const int* t_base, int t_off, int* err, void* stream) {
-    const int xs = sf_xcd_stride();
-    const size_t lds = (size_t)(L + 1) * SF_R * Hp * sizeof(float);
-    if (lds > 48 * 1024) { loc_set_error("loc_stack_forward_backward_split: nlayers too large for the LDS cache"); return -1; }
-#define LAUNCH(N)                                                                                                   \
-    hipLaunchKernelGGL((stack_fused_split_kernel<N, SF_R, 4>), dim3(32 / SF_R * 4 * xs), dim3(SF_THREADS), lds,     \
-                       (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,   \
-                       rows, Y, acts, adrop, dz, head_out, (unsigned long long*)granules, t_base, t_off, err, xs);
-    switch (Hp) {
-        case 128: LAUNCH(4); break;
-        case 256: LAUNCH(8); break;
-        case 512: LAUNCH(16); break;
-        default: loc_set_error("%s: split stack needs width 128/256/512 after padding (got %d)", __func__, Hp); return -1;
-    }
-#undef LAUNCH
-    LOC_CHECK_LAUNCH();
-    return 0;
-}
-extern "C" int loc_stack_split_enabled(int Hp) { return sf_split() == 4 && (Hp == 128 || Hp == 256 || Hp == 512); }

@@ -393,10 +393,7 @@ extern "C" int loc_head_train(const float* a, int Hp, int n_b, const int32_t* ro
                               int t_off, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_head_train: n_b=%d out of 1..32", n_b); return -1; }
     const size_t hlds = ((size_t)32 * (Hp + 1) + 2 * Hp) * sizeof(float);
-    {
-        static size_t lds_set = 0;
-        if (hlds > lds_set) { int rc = set_max_lds2(head_train_kernel, hlds); if (rc) return rc; lds_set = hlds; }
-    }
+    LOC_ENSURE_LDS(head_train_kernel, hlds);
     hipLaunchKernelGGL(head_train_kernel, dim3(1), dim3(512), hlds, (hipStream_t)stream, a, Hp, n_b, rows, Y, wa, ba,
                        wb, bb, m, v, off_wa, off_ba, off_wb, off_bb, dz_last, loss_out, alpha_tab, alpha_tab_len,
                        lr, t_base, t_off);

@@ -19,6 +19,7 @@ LOC_ROWS = 32
 LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
+LOC_GEMM_MIN_ROWS = 768  # include/locator_hip.h
 
 
 def _ptr(t):
@@ -49,7 +50,11 @@ class LocatorNet:
     """BatchNormalization -> nlayers x Dense(width, elu) with Dropout in the middle -> Dense(2) -> Dense(2),
     Adam, Euclidean loss — the model of locator.py:311-327, resident on one GPU."""
 
-    def __init__(self, X, Y, K, width=256, nlayers=10, dropout_prop=0.25, seed=0, replicate=0, device="cuda:0"):
+    def __init__(self, X, Y, K, width=256, nlayers=10, dropout_prop=0.25, seed=0, replicate=0, device="cuda:0",
+                 predict_pieces=3, tuning=None):
+        """predict_pieces: bf16 pieces per weight in the large-M inference forward (3 = exact fp32 products; 1 or 2
+        trade accuracy for speed, -1 keeps every row block on the 32-row fp32-MFMA kernel).  tuning: dict of
+        loc_tuning fields (include/locator_hip.h) - speed hints and measurement switches, never results."""
         require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -81,28 +86,10 @@ class LocatorNet:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
-        # bf16 pieces per weight in the large-M inference forward (3 = exact fp32 products; see
-        # include/locator_hip.h loc_l1_forward_rows).  LOC_PREDICT_PIECES=1|2 trades accuracy for speed,
-        # -1 keeps every row block on the 32-row fp32-MFMA kernel.
-        import os
-        self.predict_pieces = int(os.environ.get("LOC_PREDICT_PIECES", "3"))
+        self.predict_pieces = int(predict_pieces)
+        self.tuning = _lib.Tuning(**{k: int(v) for k, v in (tuning or {}).items()})
+        self.l1_image = None               # bf16 image of s_k*W1 for many-row predicts (allocated on first use)
         self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
-        # side stream + fork/join events: hidden-layer dW/Adam overlaps the layer-1 backward
-        # Opt-in (LOC_SIDE_STREAM=1).  Measured both ways: forked before the layer-1 backward (they fight for
-        # HBM and CUs) and forked after it / joined before the next stack kernel (144.9k vs 151.4k samples/s
-        # without): the cross-stream graph edges and contention with the forward cost more than the 10 us.
-        import os
-        self.side_stream = (torch.cuda.Stream(device=dev)
-                            if self.use_fused and os.environ.get("LOC_SIDE_STREAM", "0") == "1" else None)
-        self._ev_fork, self._ev_join = C.c_void_p(), C.c_void_p()
-        if self.side_stream is not None:
-            _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_fork)), "event")
-            _lib.check(self.lib.loc_event_create_notiming(C.byref(self._ev_join)), "event")
-        # split-K hidden stack (experimental, LOC_STACK_SPLIT=4): zeroed hand-off buffer + error word
-        self.gran = self.stack_err = None
-        if self.use_fused and self.lib.loc_stack_split_enabled(self.d.Hp):
-            self.gran = torch.zeros(self.lib.loc_stack_split_bytes(self.d.Hp), dtype=torch.uint8, device=dev)
-            self.stack_err = torch.zeros(1, dtype=torch.int32, device=dev)
         self._net = None
         self.init_weights()
 
@@ -117,8 +104,6 @@ class LocatorNet:
                                  "(33..64, 97..128 or 225..256)")
             if self.drop_p > 0 and self.d.n_pre < 2:
                 raise ValueError("--batch_size > 32 with dropout needs --nlayers >= 4")
-            if self.side_stream is not None or self.gran is not None:
-                raise ValueError("--batch_size > 32 is not available with LOC_SIDE_STREAM / LOC_STACK_SPLIT")
         self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
         self._net = None
         return self.slot_rows
@@ -134,13 +119,12 @@ class LocatorNet:
         n.drop_p = self.drop_p
         n.wht = self.wht.data_ptr() if self.wht is not None else None
         n.ws = self.ws.data_ptr()
-        if self.side_stream is not None:
-            n.side_stream, n.ev_fork, n.ev_join = self.side_stream.cuda_stream, self._ev_fork, self._ev_join
-        if self.gran is not None:
-            n.gran, n.stack_err = self.gran.data_ptr(), self.stack_err.data_ptr()
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         n.slot_rows = self.slot_rows
         n.predict_pieces = self.predict_pieces
+        if self.l1_image is not None:
+            n.l1_image, n.l1_image_bytes = self.l1_image.data_ptr(), self.l1_image.numel()
+        n.tune = self.tuning
         self._net = n
         return n
 
@@ -204,11 +188,9 @@ class LocatorNet:
         return out
 
     def export_params(self):
-        self.join_side()
         return self._export_flat(self.params)
 
     def export_adam(self):
-        self.join_side()
         return self._export_flat(self.adam_m, False), self._export_flat(self.adam_v, False)
 
     def _import_flat(self, flat, p, with_moving=True):
@@ -239,21 +221,14 @@ class LocatorNet:
         self.refresh_transposed()
 
     # ------------------------------------------------------------------ ops
-    def join_side(self):
-        """Make the current stream wait for the last step's side-stream work (hidden-layer dW/Adam)."""
-        if self.side_stream is not None:
-            net = self._net or self.cnet()
-            _lib.check(self.lib.loc_train_join(C.byref(net), _stream()), "loc_train_join")
-
-    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None,
-                   wait_side=True):
+    def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None):
         """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
         mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view.
         bn_ready / bn_next: epoch-level BN statistics (see epoch_bn_stats)."""
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_train_step(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
-                                           _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next),
-                                           1 if wait_side else 0, ev0, ev1, _stream()), "loc_train_step")
+                                           _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next), ev0, ev1, _stream()),
+                   "loc_train_step")
 
     def epoch_bn_stats(self, rows_all, batch, n_last, n_steps, stats_ep):
         """BN batch statistics of every minibatch of the epoch in one launch, the epoch's moving-statistics
@@ -268,7 +243,12 @@ class LocatorNet:
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
-        self.join_side()
+        if (n >= LOC_GEMM_MIN_ROWS and self.l1_image is None and self.predict_pieces > 0
+                and self.lib.loc_l1_gemm_supported(self.d.Hp, self.predict_pieces)):
+            # many rows: W1 is converted once per call into this buffer (include/locator_hip.h, loc_net.l1_image)
+            self.l1_image = torch.empty(self.lib.loc_l1_image_bytes(C.byref(self.d), self.predict_pieces),
+                                        dtype=torch.uint8, device=self.device)
+            self._net = None
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
                                         _ptr(dist), _stream()), "loc_predict")
@@ -280,7 +260,6 @@ class LocatorNet:
 
     def snapshot(self):
         """ModelCheckpoint(save_best_only, save_weights_only) as a device-side copy (locator.py:332-348)."""
-        self.join_side()
         if self.best is None:
             self.best = torch.empty_like(self.params)
         self.best.copy_(self.params)

@@ -64,7 +64,7 @@ class EpochRunner:
     """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
 
     def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True):
-        self.slot_rows = net.set_batch(int(batch_size))      # validates 1..64 and the shape constraints
+        self.slot_rows = net.set_batch(int(batch_size))      # validates 1..128 and the shape constraints
         self.net = net
         dev = net.device
         self.batch = int(batch_size)
@@ -100,8 +100,7 @@ class EpochRunner:
             e0, e1 = (ev[j] if ev is not None else (None, None))
             nxt = self.stats_ep[(j + 1) * sz:] if j + 1 < self.steps else None
             net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
-                           bn_ready=True, bn_next=nxt, wait_side=j > 0)
-        net.join_side()          # the last step's side-stream dW/Adam, before validation reads the weights
+                           bn_ready=True, bn_next=nxt)
         if self.n_val:
             net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
         net.t_base_t.add_(self.steps)

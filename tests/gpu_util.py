@@ -31,14 +31,14 @@ def randomize_params(p, rng, round_fp32=True):
     return p
 
 
-def build_net(x, y, p, drop_p=0.25, seed=1):
+def build_net(x, y, p, drop_p=0.25, seed=1, **net_kw):
     from locator_amd.net import LocatorNet, upload_genotypes
     K = x.shape[1]
     width = p["W"][0].shape[1]
     nlayers = len(p["W"]) - 2
     X = upload_genotypes(x)
     Y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).cuda()
-    net = LocatorNet(X, Y, K, width, nlayers, drop_p, seed=seed)
+    net = LocatorNet(X, Y, K, width, nlayers, drop_p, seed=seed, **net_kw)
     net.import_params(O.cast_params(p, np.float32))
     return net
 

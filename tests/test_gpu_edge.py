@@ -136,60 +136,46 @@ def test_unsupported_configurations_are_rejected_with_messages():
     EpochRunner(LocatorNet(X, Y, 40, 64, 3, 0.0), tr, va, 40)          # no dropout: any depth >= 2 is fine
 
 
-_KNOB_PROBE = r"""
-import hashlib, numpy as np, torch
-from tests.gpu_util import build_net, make_problem
-from locator_amd.train import EpochRunner
-x, y, p, rng = make_problem(70, 4096, 256, 4, seed=3)
-net = build_net(x, y, p, drop_p=0.25, seed=7)
-runner = EpochRunner(net, np.arange(60), np.arange(60, 70), 32, use_graph=False)
-out = []
-for e in range(2):
-    out.append(runner.run_epoch(np.random.default_rng(e).permutation(60)))
-torch.cuda.synchronize()
-print("DIGEST", hashlib.sha1(net.params.cpu().numpy().tobytes()).hexdigest(), repr(out))
-"""
+def _two_epochs(tuning):
+    from locator_amd.train import EpochRunner
+    x, y, p, rng = make_problem(70, 4096, 256, 4, seed=3)
+    net = build_net(x, y, p, drop_p=0.25, seed=7, tuning=tuning)
+    runner = EpochRunner(net, np.arange(60), np.arange(60, 70), 32, use_graph=False)
+    out = [runner.run_epoch(np.random.default_rng(e).permutation(60)) for e in range(2)]
+    torch.cuda.synchronize()
+    return net.params.cpu().numpy().copy(), out
 
 
-def _probe(env):
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-c", _KNOB_PROBE], cwd=root, env=e, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
-
-
-def test_speed_knobs_do_not_change_a_single_bit():
-    """Cache policy of the layer-1 backward (LOC_L1B_NT), XCD placement / L2 warm-up helpers of the hidden
-    stack (LOC_STACK_XCD_STRIDE, LOC_STACK_HELPERS) are speed hints: two epochs of training (width 256, the
-    shape the knobs apply to) must leave bit-identical weights, losses and validation losses."""
-    ref = _probe({})
-    assert _probe({"LOC_L1B_NT": "0"}) == ref
-    assert _probe({"LOC_L1B_NT": "15"}) == ref
-    assert _probe({"LOC_STACK_XCD_STRIDE": "1", "LOC_STACK_HELPERS": "0"}) == ref
-    assert _probe({"LOC_STACK_HELPERS": "3"}) == ref
-    # opt-in experiments kept in the tree (DESIGN.md §5): the side-stream overlap only reorders launches ->
-    # identical bits; the split-K hidden stack changes the summation order -> same losses to 1e-5
-    assert _probe({"LOC_SIDE_STREAM": "1"}) == ref
-    split = _probe({"LOC_STACK_SPLIT": "4"})
-    a = np.array(eval(ref.split(" ", 2)[2]))
-    b = np.array(eval(split.split(" ", 2)[2]))
-    assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-5, (a, b)
+def test_speed_hints_do_not_change_a_single_bit():
+    """loc_tuning (include/locator_hip.h): the cache policy of the layer-1 backward (l1b_nt_mask) and the XCD
+    placement / L2 warm-up helpers of the hidden stack (stack_xcd_stride, stack_helpers) are speed hints passed
+    explicitly in loc_net.tune - the library reads no environment.  Two epochs of training at width 256 (the shape
+    the hints apply to) must leave bit-identical weights, losses and validation losses."""
+    ref_w, ref_out = _two_epochs(None)
+    for tuning in ({"l1b_nt_mask": -1}, {"l1b_nt_mask": 15}, {"l1b_nt_mask": 9},
+                   {"stack_xcd_stride": 1, "stack_helpers": -1}, {"stack_helpers": 3}, {"stack_xcd_stride": 2}):
+        w, out = _two_epochs(tuning)
+        assert np.array_equal(w, ref_w) and out == ref_out, tuning
 
 
 def test_row_block_backward_meets_the_single_step_parity_bar():
-    """The bf16x3 row-block backward (normally used above 32 rows) pushed through the strictest parity tests of
-    the default kernel: LOC_L1B_ROWS=1 routes <= 32-row steps of width 256 through it as one row block.  One
-    training step within 1e-5 of the fp64 oracle on every weight, five steps, and the golden fixtures."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_golden.py", "-m", "gpu",
-                        "-q", "-x", "-p", "no:cacheprovider", "-k", "one_training_step or five_steps or hip_path"],
-                       cwd=root, env=dict(os.environ, LOC_L1B_ROWS="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    """The bf16x3 row-block backward (normally used above 32 rows) pushed through the strictest parity bar of the
+    default kernel: loc_tuning.l1b_rows = 1 routes <= 32-row steps of width 256 through it as one row block.  One
+    training step within 1e-5 of the fp64 oracle on every weight and loss within 2e-5, three consecutive steps."""
+    K, width, nlayers = 5830, 256, 10
+    x, y, p, rng = make_problem(64, K, width, nlayers, seed=K)
+    net = build_net(x, y, p, drop_p=0.25, tuning={"l1b_rows": 1})
+    pr = O.copy_params(p)
+    m, v = O.zeros_like_trainable(pr), O.zeros_like_trainable(pr)
+    for t, n_b in enumerate((32, 21, 32), start=1):
+        idx = rng.choice(64, n_b, replace=False)
+        mask_np = (rng.random((32, width)) >= 0.25).astype(np.uint8)
+        rows = np.zeros(32, np.int32)
+        rows[:n_b] = idx
+        loss = torch.zeros(1, device="cuda")
+        net.train_step(torch.from_numpy(rows).cuda(), n_b, t, torch.from_numpy(mask_np).cuda(), loss)
+        torch.cuda.synchronize()
+        ref = O.train_step(pr, m, v, t, 1e-3, x[idx], y[idx], mask_np[:n_b, :width], 0.25)
+        assert abs(loss.item() - ref) < 2e-5 * max(1, abs(ref))
+        errs = params_err(net.export_params(), pr)
+        assert max(errs.values()) < (1e-5 if t == 1 else 2e-5), (t, errs)

@@ -38,7 +38,7 @@ def _run_rows(net, rows, n, pieces, target_blocks=0, scratch_tiles=512):
     a1 = torch.full((mp, d.Hp), float("nan"), device="cuda")
     _lib.check(net.lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n, C.byref(d),
                                            bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1, partial.data_ptr(),
-                                           partial.numel(), a1.data_ptr(), pieces, target_blocks, None),
+                                           partial.numel(), a1.data_ptr(), pieces, target_blocks, None, None),
                "loc_l1_forward_rows")
     torch.cuda.synchronize()
     return a1.cpu().numpy()

@@ -1,14 +1,12 @@
 #!/bin/bash
-# PMC passes on tools/gemm_variants.py (GPU box, repo root): bash tools/gemm_pmc.sh "<variant list>" [pieces]
+# PMC passes on the image-based GEMM (GPU box, repo root): bash tools/gemm_pmc.sh  ->  gpurun_out/gemm_pmc.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-V=${1:-0}
-PZ=${2:-1,3}
 rm -rf $O/gp1 $O/gp2 $O/gp3
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $O/gp1 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $O/gp2 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL -d $O/gp3 -o p --output-format csv -- python3 $R/tools/gemm_variants.py --variants $V --pieces $PZ --iters 3 > $O/gp3.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $O/gp1 -o p --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000 --iters 3 --gemm-only > $O/gp1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $O/gp2 -o p --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000 --iters 3 --gemm-only > $O/gp2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL -d $O/gp3 -o p --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000 --iters 3 --gemm-only > $O/gp3.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rows", default="1000,450,90")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--blocks", default="0")
+    ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMM (l1_gemm.hip)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n_max = max(int(r) for r in a.rows.split(","))
@@ -43,7 +44,7 @@ def main():
                                             P + 4 * lay.mov_var, bn4.data_ptr(), None))
     partial = torch.empty(512 * 128 * d.Hp, device=dev)
     out = []
-    for n in [int(r) for r in a.rows.split(",")]:
+    for n in ([] if a.gemm_only else [int(r) for r in a.rows.split(",")]):
         rows = torch.arange(n, dtype=torch.int32, device=dev)
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for blocks in [int(b) for b in a.blocks.split(",")]:
@@ -55,7 +56,7 @@ def main():
                     _lib.check(lib.loc_l1_forward_rows(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
                                                        bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
                                                        partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces,
-                                                       blocks, None))
+                                                       blocks, None, None))
                 for _ in range(5):
                     run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
