@@ -1,31 +1,43 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training samples/s of one locator model fit on a synthetic
-1,000-individual x 100,000-SNP genotype matrix (BASELINE.json configs[2]), per GPU.
+"""Headline benchmark: training samples/s of locator model fits on a synthetic 1,000-individual x 100,000-SNP
+genotype matrix (BASELINE.json configs[2]).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" here is ONE EPOCH of model.fit on the 810-row training split: 26 minibatch steps of
-batch 32 (25 full + one of 10, kept as Keras keeps it), the validation sweep over the 90 held-out
-rows, and the host-side callbacks (ModelCheckpoint snapshot when val_loss improves, LR plateau).
-Inputs (genotypes, targets, weights) are resident in HBM before the timed region starts.
+A "step" is ONE EPOCH of model.fit on the 810-row training split: 26 minibatch steps of batch 32 (25 full + one of
+10, kept as Keras keeps it), the validation sweep over the 90 held-out rows, and the host-side callbacks
+(ModelCheckpoint snapshot when val_loss improves, LR plateau).  Inputs (genotypes, targets, weights) are resident
+in HBM before the timed region starts.
 
-N > 1: one process per GPU, each fitting its OWN bootstrap replicate of the same matrix
-(locator.py:635-681: replicates are independent fits) — no data-path collective; torch.distributed
-is used only for the barrier and the max-over-ranks of the elapsed time.  scaling = "weak".
+N > 1: one process per GPU, each fitting its OWN bootstrap replicate of the same matrix (locator.py:635-681:
+replicates are independent fits) - no data-path collective; torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.  scaling = "weak".  Launched under torch.distributed.run the ranks come from
+the environment; launched plainly with --gpus N > 1, this script starts the N rank processes itself (before it
+touches any GPU) and relays rank 0's line.
+
+--replicates-per-gpu R: R independent fits per process, each on its own HIP stream with its own captured epoch
+graph, started together (the latency-bound hidden stack of one fit overlaps the HBM-bound layer-1 kernels of the
+other); value counts the samples of all of them.  The headline configuration is R = 1.
 
 The JSON line also carries
-  roofline      the dominant kernel (l1_bwd_adam: fused layer-1 backward + Adam), algorithmic bytes per
-                launch / its mean duration from HIP events recorded on the launch stream immediately before and
-                after that kernel, vs 8 TB/s HBM; `traffic` = PMC-measured bytes (profiles/r01_pmc_traffic.json)
-  cpu_baseline  the NumPy fp32 port of the same step (oracle/) timed on this box's host cores on a
-                bounded sample of the same workload.
-  l1_gemm       (N=1) the large-M first-layer genotype GEMM of the predict / validation sweeps over all rows,
-                as a fraction of the dense bf16-MFMA peak (outside the timed region; events on the stream).
+  roofline      the dominant kernel (l1_bwd_adam: fused layer-1 backward + Adam): algorithmic bytes per launch / its
+                mean duration from HIP events recorded on the launch stream immediately before and after that
+                kernel, vs 8 TB/s HBM.  `traffic` = PMC-measured bytes per launch from the committed rocprofv3
+                passes (profiles/r02_pmc_traffic.json), reported only while the kernel sources still hash to what
+                was profiled (`traffic_source` says which).
+  cpu_baseline  the torch-CPU fp32 restatement of the same epochs (oracle/torch_cpu.py: "restated reference on CPU
+                (torch), not TensorFlow") on this box's physical cores, validation sweep included,
+                bounded to ~12 s; `numpy_port` = the single-threaded-Adam NumPy oracle step for comparison.
+  l1_gemm       (N=1) the large-M first-layer genotype GEMM (model.predict over all 1000 rows) as a fraction of the
+                dense bf16-MFMA peak: image + GEMM path (l1_gemm.hip) and the in-loop-conversion kernel.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +48,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (no sparsity)
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
+TRAFFIC_SOURCES = ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/common.h")
 
 
 def l1_bwd_bytes(K, H, n_b):
@@ -50,10 +64,61 @@ def step_bytes(K, H, n_b, L=10):
     return 28 * K * H + 2 * n_b * K + 64 * K + 28 * ((L - 1) * H * H + (L + 1) * H + 8)
 
 
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(K, H, n):
+    """PMC bytes per l1_bwd_adam launch from the committed profile, or (None, why) when it does not describe the
+    kernel that is running now."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return None, f"{TRAFFIC_PROFILE} missing"
+    if pm.get("workload") != {"K": K, "H": H, "n": n}:
+        return None, f"{TRAFFIC_PROFILE} is for another workload"
+    if pm.get("kernel_sources_sha256_16") != kernel_sources_sha():
+        return None, f"{TRAFFIC_PROFILE} was taken on other kernel sources (re-run tools/pmc_traffic.sh)"
+    key = [k for k in pm["kernels"] if k.startswith("l1_bwd_adam_kernel<%d" % ((H + 31) // 32))]
+    if not key:
+        return None, "kernel not in profile"
+    return int(pm["kernels"][key[0]]["traffic_bytes"]), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, sources {pm['kernel_sources_sha256_16']})"
+
+
+def _time_graphed(fn, iters):
+    """Mean microseconds of fn() (which enqueues on the current stream), replayed from a captured HIP graph so host
+    launch overhead does not pad kernel time."""
+    import torch
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.synchronize()
+        e0.record(s)
+        g.replay()
+        e1.record(s)
+        s.synchronize()
+    torch.cuda.current_stream().wait_stream(s)
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
 def l1_gemm_roofline(net, n_rows, iters=20):
-    """The only large-M contraction on the path (model.predict / validation, locator.py:414, :441):
-    a1 = ELU(BN(x) W1 + b1) for n_rows rows at once through loc_l1_forward_rows, timed with HIP events.
-    flops = 2*M*K*H counted ONCE, however many bf16 pieces carry each fp32 weight (3 = exact products)."""
+    """The only large-M contraction on the path (model.predict / --jacknife, locator.py:414, :441, :683-747):
+    a1 = ELU(BN(x) W1 + b1) for n_rows rows at once.  flops = 2*M*K*H counted ONCE, however many bf16 pieces carry
+    each fp32 weight (3 = exact products).  `gemm`: weights converted once per sweep (us_prep, not in us) and the
+    pure-MFMA GEMM + its reduction (us); `in_loop`: loc_l1_forward_rows, which converts inside the K loop."""
     import ctypes as C
 
     import torch
@@ -61,89 +126,112 @@ def l1_gemm_roofline(net, n_rows, iters=20):
     lib, d, lay = net.lib, net.d, net.lay
     P = net.params.data_ptr()
     dev = net.params.device
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     bn4 = torch.zeros(4 * d.Kp, device=dev)
     _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
-                                            P + 4 * lay.mov_var, bn4.data_ptr(), None))
+                                            P + 4 * lay.mov_var, bn4.data_ptr(), st()))
     partial = torch.empty(256 * 128 * d.Hp, device=dev)
     rows = torch.arange(n_rows, dtype=torch.int32, device=dev)
     a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
-    out = {"rows": n_rows, "flops": 2.0 * n_rows * d.K * d.H, "bytes": float(n_rows * d.K + 4 * d.K * d.H),
-           "peak_tflops": BF16_PEAK_TFLOPS, "kernel": "l1_rows_partial_kernel + l1_reduce_kernel"}
-    for pieces in (3, 1):
-        if not lib.loc_l1_rows_supported(d.Hp, pieces):
-            continue
+    flops = 2.0 * n_rows * d.K * d.H
+    out = {"rows": n_rows, "flops": flops, "peak_tflops": BF16_PEAK_TFLOPS,
+           "kernel": "l1_gemm_kernel + l1_gemm_reduce_kernel (weights converted once per sweep by l1_image_kernel)"}
 
-        def run():
-            _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
-                                               C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
-                                               partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces, 0, None,
-                                               None))
-        for _ in range(3):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        tf = out["flops"] / us * 1e-6
-        out["bf16x%d" % pieces] = {"us": round(us, 1), "tflops": round(tf, 1),
-                                   "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
-                                   "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4),
-                                   "hbm_gbs": round(out["bytes"] / us * 1e-3, 1),
-                                   "exact_fp32_products": pieces == 3}
+    def rec(us, pieces, byts):
+        tf = flops / us * 1e-6
+        return {"us": round(us, 1), "tflops": round(tf, 1), "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
+                "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1),
+                "exact_fp32_products": pieces == 3}
+
+    for pieces in (3, 1):
+        key = "bf16x%d" % pieces
+        if lib.loc_l1_gemm_supported(d.Hp, pieces):
+            image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
+            prep = lambda: _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
+                                                             image.data_ptr(), st()))
+            run = lambda: _lib.check(lib.loc_l1_forward_gemm(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
+                                                             C.byref(d), image.data_ptr(), pieces, P + 4 * lay.b1,
+                                                             partial.data_ptr(), partial.numel(), a1.data_ptr(), 0, st()))
+            prep()
+            us_prep = _time_graphed(prep, 10)
+            us = _time_graphed(run, iters)
+            r = rec(us, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
+            r["us_prep"] = round(us_prep, 1)
+            r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
+            out[key] = r
+            del image
+        if lib.loc_l1_rows_supported(d.Hp, pieces):
+            run = lambda: _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
+                                                             C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
+                                                             partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces,
+                                                             0, None, st()))
+            out.setdefault("in_loop_conversion", {})[key] = rec(_time_graphed(run, iters), pieces,
+                                                                n_rows * d.K + 4.0 * d.K * d.H)
     return out
 
 
-def cpu_baseline(x, y_norm, train, K, H, seconds=20.0):
-    """Oracle (NumPy fp32 port of the same training step) on the host cores; bounded sample."""
+def cpu_baseline(x, y_norm, train, test, K, H, seconds):
+    """torch-CPU fp32 restatement of the same epochs on the host's physical cores (oracle/torch_cpu.py), plus the NumPy
+    oracle's step rate as a second, smaller figure.  Bounded sample."""
     from oracle import locator_oracle as O
+    from oracle import torch_cpu
+    out = torch_cpu.time_epochs(x, y_norm, train, test, K, H, seconds=seconds)
     rng = np.random.default_rng(0)
     p = O.init_params(K, H, 10, rng, dtype=np.float32)
     m, v = O.zeros_like_trainable(p), O.zeros_like_trainable(p)
     xt, yt = x[train], y_norm[train].astype(np.float32)
-    n_done, t_used, t = 0, 0.0, 0
-    perm = rng.permutation(len(train))
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        rows = perm[(steps * 32) % (len(train) - 32):][:32]
-        mask = rng.random((32, H)) >= 0.25
-        t += 1
-        O.train_step(p, m, v, t, np.float32(1e-3), xt[rows], yt[rows], mask, 0.25)
+    steps, t0 = 0, time.perf_counter()
+    while steps < 3 or time.perf_counter() - t0 < 4.0:
+        rows = rng.choice(len(train), 32, replace=False)
+        O.train_step(p, m, v, steps + 1, np.float32(1e-3), xt[rows], yt[rows], rng.random((32, H)) >= 0.25, 0.25)
         steps += 1
-        n_done += 32
-        t_used = time.perf_counter() - t0
-        if t_used >= seconds and steps >= 3:
-            break
-    try:
-        import threadpoolctl
-        cores = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": n_done / t_used, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{steps} minibatch steps of 32 rows x {K} SNPs (NumPy fp32 oracle, BLAS threads = cores), "
-                      f"{t_used:.1f} s; validation sweep not included"}
+    out["numpy_port"] = {"value": round(32 * steps / (time.perf_counter() - t0), 1), "unit": "samples/s",
+                         "sample": f"{steps} minibatch steps, NumPy fp32 oracle (BLAS contractions, single-threaded "
+                                   "elementwise Adam), no validation sweep"}
+    out["value"] = round(out["value"], 1)
+    return out
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start the N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment) and relay rank 0's output.  Runs before this process has touched a GPU and never touches one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed epochs")
-    ap.add_argument("--warmup", type=int, default=3, help="untimed epochs")
+    ap.add_argument("--steps", type=int, default=100, help="timed epochs (5 ms each on one MI355X)")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed epochs")
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--snps", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32, help="--batch_size of the fit (headline: 32, the reference default)")
+    ap.add_argument("--replicates-per-gpu", type=int, default=1, help="independent fits per process on separate streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-l1-gemm", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing)")
     ap.add_argument("--device-index", type=int, default=None,
                     help="testing: put every rank on this GPU instead of LOCAL_RANK")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -153,8 +241,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if args.device_index is not None:
         local = args.device_index
@@ -172,31 +259,55 @@ def main():
     from locator_amd.synth import normalize_locs, split_indices, synth_genotypes
     from locator_amd.train import Callbacks, EpochRunner
 
-    K, H, n = args.snps, args.width, args.n
+    K, H, n, R = args.snps, args.width, args.n, max(1, args.replicates_per_gpu)
     x, locs = synth_genotypes(n, K, seed=20260101, n_na=n // 10)
     train, test, pred = split_indices(locs, 0.9, seed=12345)
     _, _, _, _, ynorm = normalize_locs(locs)
-    X = upload_genotypes(x, dev)
-    if world > 1 or rank > 0:
-        # every rank fits its own bootstrap replicate: resample SNP columns on device (locator.py:648-653)
-        so = np.random.RandomState(1000 + rank).choice(K, K, replace=True)
-        X = gather_columns(X, so, K)
+    X0 = upload_genotypes(x, dev)
     Y = torch.from_numpy(np.nan_to_num(ynorm).astype(np.float32)).to(dev)
-    net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=rank, device=dev)
-    runner = EpochRunner(net, train, test, args.batch, use_graph=not args.no_graph)
-    cb = Callbacks(100, 1e-3)
-    rng = np.random.default_rng(99 + rank)
-    n_train, steps_per_epoch = runner.n_train, runner.steps
-    hist = []
 
-    def epoch(e, ev=None):
-        loss, val = runner.run_epoch(rng.permutation(n_train), ev)
-        save, stop, lr_logged = cb.on_epoch_end(e, val)
-        if save:
-            net.snapshot()
-        if cb.lr != lr_logged:
-            net.lr_t.fill_(cb.lr)
-        hist.append((loss, val))
+    class Fit:
+        """One model fit: its matrix (a bootstrap resample unless it is THE single fit), net, epoch runner, callbacks
+        and stream."""
+
+        def __init__(self, replicate):
+            X = X0
+            if world > 1 or R > 1 or replicate > 0:
+                # every replicate resamples the SNP columns on device (locator.py:648-653)
+                so = np.random.RandomState(1000 + replicate).choice(K, K, replace=True)
+                X = gather_columns(X0, so, K)
+            self.net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=replicate, device=dev)
+            self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph)
+            self.cb = Callbacks(100, 1e-3)
+            self.rng = np.random.default_rng(99 + replicate)
+            self.stream = torch.cuda.Stream(device=dev) if R > 1 else torch.cuda.current_stream()
+            self.hist = []
+            self.e = 0
+
+        def start(self, ev=None):
+            with torch.cuda.stream(self.stream):
+                self.runner.start_epoch(self.rng.permutation(self.runner.n_train), ev)
+
+        def finish(self):
+            with torch.cuda.stream(self.stream):
+                loss, val = self.runner.finish_epoch()
+                save, stop, lr_logged = self.cb.on_epoch_end(self.e, val)
+                if save:
+                    self.net.snapshot()
+                if self.cb.lr != lr_logged:
+                    self.net.lr_t.fill_(self.cb.lr)
+            self.hist.append((loss, val))
+            self.e += 1
+
+    fits = [Fit(rank * R + r) for r in range(R)]
+    torch.cuda.synchronize()
+    n_train, steps_per_epoch = fits[0].runner.n_train, fits[0].runner.steps
+
+    def epoch(ev=None):
+        for f in fits:
+            f.start(ev)
+        for f in fits:
+            f.finish()
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,15 +315,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    e = 0
-    for _ in range(max(args.warmup, 2)):       # epoch 0 eager, epoch 1 captures the graph
-        epoch(e)
-        e += 1
+    warm = max(args.warmup, 2)                 # epoch 0 eager, epoch 1 captures the graph
+    for _ in range(warm):
+        epoch()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        epoch(e)
-        e += 1
+        epoch()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -225,6 +334,7 @@ def main():
     if rank == 0:
         lib = _lib.load()
         import ctypes as C
+        f0 = fits[0]
         n_ep = 2
         evs = []
         for _ in range(n_ep * steps_per_epoch * 2):
@@ -235,53 +345,49 @@ def main():
         for k in range(n_ep):
             pairs = [(evs[2 * (k * steps_per_epoch + j)], evs[2 * (k * steps_per_epoch + j) + 1])
                      for j in range(steps_per_epoch)]
-            epoch(e, pairs)
-            e += 1
+            f0.start(pairs)
+            f0.finish()
             for j, (a, b) in enumerate(pairs):
-                out = C.c_float()
-                _lib.check(lib.loc_event_elapsed_ms(a, b, C.byref(out)))
-                ms.append(out.value)
-                by.append(l1_bwd_bytes(K, H, int(runner.step_sizes[j])))
+                o = C.c_float()
+                _lib.check(lib.loc_event_elapsed_ms(a, b, C.byref(o)))
+                ms.append(o.value)
+                by.append(l1_bwd_bytes(K, H, int(f0.runner.step_sizes[j])))
         for h in evs:
             lib.loc_event_destroy(h)
         t_mean = float(np.mean(ms)) * 1e-3
         achieved = float(np.mean(by)) / t_mean / 1e9
-        traffic = None
-        try:    # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm["workload"] == {"K": K, "H": H, "n": n}:
-                key = [k for k in pm["kernels"] if k.startswith("l1_bwd_adam_kernel<%d" % ((H + 31) // 32))][0]
-                traffic = int(pm["kernels"][key]["traffic_bytes"])
-        except Exception:
-            traffic = None
+        traffic, traffic_source = measured_traffic(K, H, n)
         roof = {"bound": "hbm", "kernel": "l1_bwd_adam_kernel", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": int(np.mean(by)), "us_per_launch": round(t_mean * 1e6, 2),
-                "launches_timed": len(ms)}
+                "traffic_source": traffic_source, "bytes_per_launch": int(np.mean(by)),
+                "us_per_launch": round(t_mean * 1e6, 2), "launches_timed": len(ms)}
 
     if rank == 0:
-        value = world * args.steps * n_train / elapsed
+        value = world * R * args.steps * n_train / elapsed
         ms_epoch = elapsed / args.steps * 1e3
-        step_b = sum(step_bytes(K, H, int(s)) for s in runner.step_sizes)
+        step_b = sum(step_bytes(K, H, int(s)) for s in fits[0].runner.step_sizes)
         out = {
             "metric": "training samples/sec on 1000x100k-SNP matrix",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": max(args.warmup, 2), "ms_per_step": round(ms_epoch, 4), "higher_is_better": True,
+            "warmup": warm, "ms_per_step": round(ms_epoch, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {n} ind x {K} SNPs uint8 (BASELINE.json configs[2]), single model "
-                                   f"fit per GPU, batch {args.batch}, {n_train} train / {len(test)} validation",
-                       "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + callbacks",
-                       "width": H, "nlayers": 10, "graph": not args.no_graph,
-                       "replicates": "1 model per GPU, bootstrap resample per rank" if world > 1 else "single model"},
-            "us_per_minibatch_step": round(ms_epoch * 1e3 / steps_per_epoch, 2),
-            "whole_step_hbm_frac": round(step_b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            "final_loss": round(hist[-1][0], 5), "final_val_loss": round(hist[-1][1], 5),
+            "config": {"workload": f"synthetic {n} ind x {K} SNPs uint8 (BASELINE.json configs[2]), "
+                                   f"{'single model fit' if R == 1 else str(R) + ' concurrent replicate fits'} per GPU, "
+                                   f"batch {args.batch}, {n_train} train / {len(test)} validation",
+                       "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + callbacks"
+                               + ("" if R == 1 else f", of each of the {R} fits"),
+                       "width": H, "nlayers": 10, "graph": not args.no_graph, "replicates_per_gpu": R,
+                       "replicates": ("single model" if world == 1 and R == 1 else
+                                      f"{R} model(s) per GPU, bootstrap resample per replicate")},
+            "us_per_minibatch_step": round(ms_epoch * 1e3 / steps_per_epoch / R, 2),
+            "whole_step_hbm_frac": round(R * step_b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "final_loss": round(fits[0].hist[-1][0], 5), "final_val_loss": round(fits[0].hist[-1][1], 5),
             "roofline": roof,
         }
-        if world == 1:
-            out["l1_gemm"] = l1_gemm_roofline(net, n)
+        if world == 1 and not args.no_l1_gemm:
+            out["l1_gemm"] = l1_gemm_roofline(fits[0].net, n)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(x, np.nan_to_num(ynorm), train, K, H, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(x, np.nan_to_num(ynorm), train, test, K, H, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -105,8 +105,10 @@ class EpochRunner:
             net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
         net.t_base_t.add_(self.steps)
 
-    def run_epoch(self, perm, ev=None):
-        """perm: permutation of range(n_train) (Keras shuffle=True draws it unseeded; here it is an input)."""
+    def start_epoch(self, perm, ev=None):
+        """Enqueue one epoch on the CURRENT stream and return without waiting (several fits on their own streams can
+        be in flight at once, replicates.py / bench.py --replicates-per-gpu).  perm: permutation of range(n_train)
+        (Keras shuffle=True draws it unseeded; here it is an input)."""
         net = self.net
         rows = self.train_rows[np.asarray(perm)]
         self.perm_host[:self.n_train] = torch.from_numpy(rows)
@@ -117,7 +119,10 @@ class EpochRunner:
         if self.use_graph and ev is None:
             if self.graph is None and self.epochs_run >= 1:      # epoch 0 ran eagerly = warm-up
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                cur = torch.cuda.current_stream()
+                # capture is not allowed on the default stream: torch then captures on a side stream of its own
+                kw = {} if cur == torch.cuda.default_stream() else {"stream": cur}
+                with torch.cuda.graph(g, **kw):
                     self.enqueue()
                 self.graph = g
             if self.graph is not None:
@@ -127,12 +132,20 @@ class EpochRunner:
         else:
             self.enqueue(ev)
         self.stats_host.copy_(self.stats, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        self._stream = torch.cuda.current_stream()
+
+    def finish_epoch(self):
+        """Wait for the epoch started last and return (loss, val_loss) as Keras logs them."""
+        self._stream.synchronize()
         self.epochs_run += 1
         s = self.stats_host.numpy()
         loss = float(np.dot(s[:self.steps].astype(np.float64), self.step_sizes) / self.n_train)
         val = float(s[self.steps:self.steps + self.n_val].astype(np.float64).mean()) if self.n_val else float("nan")
         return loss, val
+
+    def run_epoch(self, perm, ev=None):
+        self.start_epoch(perm, ev)
+        return self.finish_epoch()
 
 
 def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, perm_fn=None,

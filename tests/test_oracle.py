@@ -178,3 +178,39 @@ def test_fp32_oracle_tracks_fp64():
     l32, g32, _ = O.loss_and_grads(O.cast_params(p, np.float32), x, y, mask)
     assert abs(l64 - l32) < 1e-5
     assert np.allclose(g64["W"][0], g32["W"][0], atol=2e-6)
+
+
+def test_torch_cpu_restatement_matches_the_numpy_oracle():
+    """oracle/torch_cpu.py (the multi-threaded torch-CPU fp32 restatement timed as bench.py's cpu_baseline) against
+    the fp64 NumPy oracle: 2 epochs with the same permutations and dropout masks, a partial last batch, and the
+    validation sweep.  fp32 vs fp64: losses 1e-4, weights 5e-5."""
+    import torch
+    from oracle.torch_cpu import TorchCpuLocator
+    rng = np.random.default_rng(5)
+    n, K, H, L = 75, 300, 32, 4
+    x = rng.integers(0, 3, (n, K)).astype(np.uint8)
+    y = rng.normal(0, 1, (n, 2))
+    p = O.init_params(K, H, L, rng)
+    p["gamma"] = rng.uniform(0.7, 1.3, K)
+    p["mov_mean"] = rng.uniform(0, 1, K)
+    tr, va = np.arange(60), np.arange(60, 75)
+    perms = [rng.permutation(60) for _ in range(2)]
+    masks = [[(rng.random((32, H)) >= 0.25) for _ in range(2)] for _ in range(2)]
+    pref = O.copy_params(p)
+    href, _ = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=32, max_epochs=2, patience=100, drop_p=0.25,
+                    perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s][:nb])
+    torch.set_num_threads(2)
+    xt, xv = torch.from_numpy(x[tr]), torch.from_numpy(x[va])
+    yt, yv = torch.from_numpy(y[tr].astype(np.float32)), torch.from_numpy(y[va].astype(np.float32))
+    for fused in (True, False):           # single-pass torch._fused_adam_ with the Keras-equivalent eps, and the foreach form
+        net = TorchCpuLocator(O.cast_params(p, np.float32), 0.25, fused=fused)
+        for e in range(2):
+            loss, val = net.fit_epoch(xt, yt, xv, yv, perms[e],
+                                      [torch.from_numpy(m.astype(np.float32)) for m in masks[e]], 1e-3)
+            assert abs(loss - href["loss"][e]) < 1e-4 and abs(val - href["val_loss"][e]) < 1e-4
+        got = net.export()
+        for k in ("gamma", "beta", "mov_mean", "mov_var"):
+            assert np.abs(got[k] - pref[k]).max() < 5e-5, (fused, k)
+        for l in range(len(pref["W"])):
+            assert np.abs(got["W"][l] - pref["W"][l]).max() < 5e-5, (fused, l)
+            assert np.abs(got["b"][l] - pref["b"][l]).max() < 5e-5, (fused, l)

@@ -12,9 +12,21 @@ usage: pmc_traffic.py <fetch_dir>/f_counter_collection.csv <write_dir>/w_counter
 (tools/pmc_traffic.sh runs the two passes and this summary)
 """
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha():
+    """Same hash bench.py computes: `traffic` is only reported while the kernel sources still match the profile."""
+    h = hashlib.sha256()
+    for rel in ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/common.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
 
 WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer")
 
@@ -45,8 +57,9 @@ def main():
     n_total = None
     cal = out.get("__amd_rocclr_copyBuffer")
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 "
-                     "bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph; tools/pmc_traffic.sh",
+                     "bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-l1-gemm --no-graph; tools/pmc_traffic.sh",
            "workload": {"K": K, "H": H, "n": n},
+           "kernel_sources_sha256_16": kernel_sources_sha(),
            "units": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled for wide (16 B/lane) streaming reads per "
                     "MI355X_MICROARCH.md (HBM section)",
            "calibration": None if cal is None else {

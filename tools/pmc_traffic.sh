@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w --output-format csv -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_w.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-l1-gemm --no-graph > $O/pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w --output-format csv -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-l1-gemm --no-graph > $O/pmc_w.log 2>&1
 python3 $R/tools/pmc_traffic.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json 100000 256 1000
