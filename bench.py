@@ -211,6 +211,29 @@ def spawn_ranks(args):
     return max(abs(rc) for rc in rcs)
 
 
+def selftest_launch(args):
+    """The N-rank control plane without a GPU: rendezvous on 127.0.0.1, barrier, MAX all-reduce of a per-rank time,
+    one JSON line from rank 0 - exactly what the timed path does around its epochs."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "max_over_ranks": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,10 +251,14 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing)")
     ap.add_argument("--device-index", type=int, default=None,
                     help="testing: put every rank on this GPU instead of LOCAL_RANK")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="testing (no GPU needed): only the rank launch + barrier + max-over-ranks plumbing, over gloo")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.selftest_launch:
+        sys.exit(selftest_launch(args))
 
     import torch
     import torch.distributed as dist

@@ -16,13 +16,14 @@ Deliberate, documented deviations:
     (same content);
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
-  * --batch_size is limited to 128 rows (the reference default is 32) and --nlayers must be >= 2;
-  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed (recorded at the end of params.json).
+  * --batch_size is limited to 128 rows (the reference default is 32; 33..128 needs a --width that pads to 64,
+    128 or 256 and --nlayers >= 4 with dropout), --nlayers must be >= 2 and --width <= 512;
+  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed / --load_weights / --predict_pieces (recorded at
+    the end of params.json).
 """
 from __future__ import annotations
 
 import argparse
-import copy
 import json
 import os
 import sys
@@ -55,7 +56,7 @@ def build_parser():
     p.add_argument("--jacknife_prop", default=0.05, type=float,
                    help="fraction of SNPs redrawn per jacknife replicate (default 0.05)")
     p.add_argument("--nboots", default=50, type=int, help="number of bootstrap / jacknife replicates (default 50)")
-    p.add_argument("--batch_size", default=32, type=int, help="minibatch size (default 32; at most 32 here)")
+    p.add_argument("--batch_size", default=32, type=int, help="minibatch size (default 32; 1..128 here)")
     p.add_argument("--max_epochs", default=5000, type=int, help="upper bound on training epochs (default 5000)")
     p.add_argument("--patience", type=int, default=100,
                    help="epochs without validation improvement before training stops (default 100)")
@@ -65,7 +66,7 @@ def build_parser():
                    help="draw missing calls from Binomial(2, site frequency) instead of counting them as 0")
     p.add_argument("--dropout_prop", default=0.25, type=float, help="dropout rate of the middle layer (default 0.25)")
     p.add_argument("--nlayers", default=10, type=int, help="number of hidden layers (default 10)")
-    p.add_argument("--width", default=256, type=int, help="units per hidden layer (default 256)")
+    p.add_argument("--width", default=256, type=int, help="units per hidden layer (default 256; at most 512 here)")
     p.add_argument("--out", help="stem of every output file")
     p.add_argument("--seed", default=None, type=int, help="NumPy seed for the train/validation split and SNP draws")
     p.add_argument("--gpu_number", default=None, type=str, help="restrict the run to this GPU index")
@@ -81,6 +82,11 @@ def build_parser():
     p.add_argument("--fits_per_gpu", default=2, type=int,
                    help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
+    p.add_argument("--load_weights", default=None, type=str,
+                   help="a .weights.npz written by --keep_weights: skip training and predict with these weights")
+    p.add_argument("--predict_pieces", default=3, type=int,
+                   help="bf16 pieces per first-layer weight in many-row predictions: 3 = fp32-exact products "
+                        "(default), 1 or 2 = faster, approximate")
     p.add_argument("--net_seed", default=None, type=int,
                    help="seed of weight init / shuffling / dropout (the reference leaves these unseeded); "
                         "default: --seed, else entropy")
@@ -91,27 +97,34 @@ args = None          # module-level namespace, as in the reference (locator.py:1
 
 
 def _setup(argv=None):
-    """locator.py:169-184 / :490-505 — seed NumPy, pick the GPU, --load_params, write params.json."""
+    """Parse flags, honour --seed / --gpu_number / --load_params and record the run in {out}_params.json
+    (what the reference does at import time, locator.py:169-184, and again at the top of main, :490-505)."""
     global args
-    args = build_parser().parse_args(argv)
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if args.load_params is not None:            # every value comes from the file; keys it lacks keep their defaults
+        merged = vars(parser.parse_args([]))
+        with open(args.load_params) as fh:
+            merged.update(json.load(fh))
+        args = argparse.Namespace(**merged)
     if args.seed is not None:
         np.random.seed(args.seed)
     if args.gpu_number is not None:
-        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu_number
-        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu_number
-    if args.load_params is not None:
-        defaults = vars(build_parser().parse_args([]))
-        with open(args.load_params, "r") as f:
-            loaded = json.load(f)
-        defaults.update(loaded)                # a reference-written json lacks the added keys
-        args.__dict__ = defaults
-    with open(args.out + "_params.json", "w") as f:
-        json.dump(args.__dict__, f, indent=2)
-    if args.net_seed is None:
-        args._net_seed = args.seed if args.seed is not None else int.from_bytes(os.urandom(4), "little")
-    else:
-        args._net_seed = args.net_seed
+        for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            os.environ[var] = args.gpu_number
+    _write_atomic(args.out + "_params.json", lambda fh: json.dump(vars(args), fh, indent=2))
+    seed = args.net_seed if args.net_seed is not None else args.seed
+    args._net_seed = seed if seed is not None else int.from_bytes(os.urandom(4), "little")
     return args
+
+
+def _write_atomic(path, writer, mode="w"):
+    """Write through a temporary file in the same directory and rename it into place: concurrent replicate workers
+    (and a reader of a half-finished run) never see a truncated file."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, mode) as fh:
+        writer(fh)
+    os.replace(tmp, path)
 
 
 # ------------------------------------------------------------------ ingest (locator.py:187-308)
@@ -134,16 +147,16 @@ def load_genotypes():
 
 
 def sort_samples(samples, genotypes):
+    """Coordinates in genotype-sample order (locator.py:231-247): the sample table is looked up by sampleID for
+    every genotype sample; an ID missing from the table aborts the run like the reference does."""
     import pandas as pd
-    sample_data = pd.read_csv(args.sample_data, sep="\t")
-    sample_data["sampleID2"] = sample_data["sampleID"]
-    sample_data.set_index("sampleID", inplace=True)
-    samples = np.asarray(samples).astype("str")
-    sample_data = sample_data.reindex(np.array(samples))
-    if not all([sample_data["sampleID2"].iloc[x] == samples[x] for x in range(len(samples))]):
+    table = pd.read_csv(args.sample_data, sep="\t")
+    ids = np.asarray(samples).astype(str)
+    sample_data = table.assign(sampleID2=table["sampleID"]).set_index("sampleID").reindex(ids)
+    if not np.array_equal(sample_data["sampleID2"].to_numpy(dtype=object).astype(str), ids):
         print("sample ordering failed! Check that sample IDs match the VCF.")
         sys.exit()
-    locs = np.array(sample_data[["x", "y"]])
+    locs = sample_data[["x", "y"]].to_numpy()
     print("loaded " + str(np.shape(genotypes)) + " genotypes\n\n")
     return sample_data, locs
 
@@ -212,7 +225,8 @@ class Model:
     def _build(self, X, Y):
         from .net import LocatorNet
         self.net = LocatorNet(X, Y, self.n_snps, self.width, self.nlayers, self.dropout_prop, seed=self.seed,
-                              replicate=self.replicate, device=self.device)
+                              replicate=self.replicate, device=self.device,
+                              predict_pieces=getattr(args, "predict_pieces", 3))
         return self.net
 
     def predict(self, gen):
@@ -253,8 +267,9 @@ def _weights_path(boot):
 
 
 def load_callbacks(boot):
-    """locator.py:330-362.  The three Keras callbacks are state machines on val_loss; they are
-    instantiated inside train.fit.  Returned here as their configuration, in the reference's order."""
+    """locator.py:330-362.  The three Keras callbacks are state machines on val_loss (train.Callbacks); what is
+    returned here, in the reference's order, is their configuration - and train_network takes it from here: editing
+    earlystop["patience"], reducelr["patience"] / ["factor"] or checkpointer["filepath"] changes the fit."""
     checkpointer = {"callback": "ModelCheckpoint", "filepath": _weights_path(boot), "save_best_only": True,
                     "save_weights_only": True, "monitor": "val_loss"}
     earlystop = {"callback": "EarlyStopping", "monitor": "val_loss", "min_delta": 0, "patience": args.patience}
@@ -263,11 +278,31 @@ def load_callbacks(boot):
     return checkpointer, earlystop, reducelr
 
 
-def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot=0):
+WEIGHT_KEYS = ("gamma", "beta", "moving_mean", "moving_variance")
+
+
+def save_weights(path, w):
+    """--keep_weights artefact: NumPy archive in Keras tensor orientation (the reference keeps a Keras HDF5 file,
+    locator.py:332-348; h5py is not available here)."""
+    flat = {"gamma": w["gamma"], "beta": w["beta"], "moving_mean": w["mov_mean"], "moving_variance": w["mov_var"]}
+    for i, (k, b) in enumerate(zip(w["W"], w["b"])):
+        flat[f"dense_{i}_kernel"], flat[f"dense_{i}_bias"] = k, b
+    _write_atomic(path, lambda fh: np.savez(fh, **flat), mode="wb")
+
+
+def read_weights(path):
+    """Inverse of save_weights: the oracle-format dict LocatorNet.import_params takes."""
+    z = np.load(path)
+    n_dense = sum(1 for k in z.files if k.endswith("_kernel"))
+    return {"gamma": z["gamma"], "beta": z["beta"], "mov_mean": z["moving_mean"], "mov_var": z["moving_variance"],
+            "W": [z[f"dense_{i}_kernel"] for i in range(n_dense)], "b": [z[f"dense_{i}_bias"] for i in range(n_dense)]}
+
+
+def _device_matrix(model, traingen, testgen, trainlocs, testlocs):
+    """Training + validation rows as ONE uint8 matrix in HBM with their z-scored targets; returns (X, Y, train row
+    range start, validation row range start)."""
     import torch
     from .net import upload_genotypes
-    from .train import fit
-    start = time.time()
     ntr, nva = traingen.shape[0], testgen.shape[0]
     if isinstance(traingen, DeviceRows):
         assert isinstance(testgen, DeviceRows) and testgen.X is traingen.X
@@ -278,74 +313,93 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
     yh = np.zeros((X.shape[0], 2), np.float32)
     yh[tr0:tr0 + ntr] = trainlocs
     yh[va0:va0 + nva] = testlocs
-    Y = torch.from_numpy(yh).to(model.device)
+    return X, torch.from_numpy(yh).to(model.device), tr0, va0
+
+
+def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot=0):
+    """model.fit with the three callbacks, then the best-val_loss weights back in the model (locator.py:365-394)."""
+    from .train import History, fit
+    start = time.time()
+    checkpointer, earlystop, reducelr = callbacks
+    ntr, nva = traingen.shape[0], testgen.shape[0]
+    if nva == 0:
+        raise SystemExit("no validation samples: --train_split leaves round((1 - split) * n_located) = 0 of them, "
+                         "and every callback of the fit monitors val_loss")
+    X, Y, tr0, va0 = _device_matrix(model, traingen, testgen, trainlocs, testlocs)
     model._build(X, Y)
     model.n_train, model.n_val = ntr, nva
-    history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
-                  max_epochs=args.max_epochs, patience=args.patience, use_graph=not args.no_graph,
-                  verbose=args.keras_verbose)
-    if args.keep_weights:          # reference: Keras HDF5 kept on disk (locator.py:332-348, :379-388)
-        w = model.weights_dict()
-        flat = {"gamma": w["gamma"], "beta": w["beta"], "moving_mean": w["mov_mean"], "moving_variance": w["mov_var"]}
-        for i, (k, b) in enumerate(zip(w["W"], w["b"])):
-            flat[f"dense_{i}_kernel"], flat[f"dense_{i}_bias"] = k, b
-        np.savez(callbacks[0]["filepath"], **flat)
-    elapsed = time.time() - start
-    print("run time " + str(elapsed / 60) + " minutes")
+    if getattr(args, "load_weights", None):
+        model.net.import_params(read_weights(args.load_weights))     # predict-only: nothing is trained
+        history = History()
+    else:
+        history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
+                      max_epochs=args.max_epochs, patience=earlystop["patience"], lr_patience=reducelr["patience"],
+                      lr_factor=reducelr["factor"], use_graph=not args.no_graph, verbose=args.keras_verbose)
+    if args.keep_weights:
+        save_weights(checkpointer["filepath"], model.weights_dict())
+    print("run time " + str((time.time() - start) / 60) + " minutes")
     return history, model
+
+
+def _predlocs_path(boot):
+    if args.bootstrap or args.jacknife:
+        return f"{args.out}_boot{boot}_predlocs.txt"
+    if args.windows:
+        # the reference appends the *flag* window to an --out that already carries the real window (SURVEY Q3)
+        w0, wsize = int(args.window_start), int(args.window_size)
+        return f"{args.out}_{w0}-{w0 + wsize - 1}_predlocs.txt"
+    return args.out + "_predlocs.txt"
+
+
+def _to_map_units(z, sdlong, meanlong, sdlat, meanlat):
+    """z-scored (n, 2) -> original coordinates, float64 like the reference's Python-float arithmetic."""
+    z = np.asarray(z, dtype=np.float64).reshape(-1, 2)
+    return z * np.array([sdlong, sdlat], dtype=np.float64) + np.array([meanlong, meanlat], dtype=np.float64)
+
+
+def write_predlocs(path, xy, sample_ids):
+    """`x,y,sampleID` CSV (locator.py:418-433), written atomically."""
+    import pandas as pd
+    frame = pd.DataFrame({"x": xy[:, 0], "y": xy[:, 1], "sampleID": np.asarray(sample_ids, dtype=object)})
+    _write_atomic(path, lambda fh: frame.to_csv(fh, index=False))
 
 
 def predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
                  boot=0, verbose=True):
+    """Predict the unknown samples, report the fit on the validation samples in map units, write
+    {out}..._predlocs.txt and {out}_history.txt (locator.py:397-470)."""
     import pandas as pd
-    from scipy import spatial
     if verbose:
         print("predicting locations...")
-    prediction = model.predict(predgen)
-    prediction = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in prediction]).reshape(-1, 2)
-    predout = pd.DataFrame(prediction)
-    predout.columns = ["x", "y"]
-    predout["sampleID"] = np.asarray(samples)[pred] if len(pred) else []
-    if args.bootstrap or args.jacknife:
-        outfile = args.out + "_boot" + str(boot) + "_predlocs.txt"
-    elif args.windows:
-        # the reference appends the *flag* window to an --out that already carries the real window
-        window_start = int(args.window_start)
-        window_size = int(args.window_size)
-        outfile = f"{args.out}_{window_start}-{window_start + window_size - 1}_predlocs.txt"
-    else:
-        outfile = args.out + "_predlocs.txt"
-    predout.to_csv(outfile, index=False)
+    xy = _to_map_units(model.predict(predgen), sdlong, meanlong, sdlat, meanlat)
+    write_predlocs(_predlocs_path(boot), xy, np.asarray(samples)[pred] if len(pred) else [])
 
-    testlocs2 = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in testlocs])
-    p2 = model.predict(testgen)
-    p2 = np.array([[x[0] * sdlong + meanlong, x[1] * sdlat + meanlat] for x in p2])
-    r2_long = np.corrcoef(p2[:, 0], testlocs2[:, 0])[0][1] ** 2
-    r2_lat = np.corrcoef(p2[:, 1], testlocs2[:, 1])[0][1] ** 2
-    dists = [spatial.distance.euclidean(p2[x, :], testlocs2[x, :]) for x in range(len(p2))]
-    mean_dist = np.mean(dists)
-    median_dist = np.median(dists)
+    truth = _to_map_units(testlocs, sdlong, meanlong, sdlat, meanlat)
+    fitted = _to_map_units(model.predict(testgen), sdlong, meanlong, sdlat, meanlat)
+    dists = np.sqrt(((fitted - truth) ** 2).sum(axis=1)).tolist()
     if verbose:
-        print("R2(x)=" + str(r2_long) + "\nR2(y)=" + str(r2_lat) + "\n" + "mean validation error " + str(mean_dist)
-              + "\n" + "median validation error " + str(median_dist) + "\n")
-    hist = pd.DataFrame(history.history)
-    hist.to_csv(args.out + "_history.txt", sep="\t", index=False)
+        r2 = [np.corrcoef(fitted[:, a], truth[:, a])[0][1] ** 2 for a in (0, 1)]
+        print(f"R2(x)={r2[0]}\nR2(y)={r2[1]}\nmean validation error {np.mean(dists)}\n"
+              f"median validation error {np.median(dists)}\n")
+    if len(history.history.get("loss", [])):
+        hist = pd.DataFrame(history.history)
+        _write_atomic(args.out + "_history.txt", lambda fh: hist.to_csv(fh, sep="\t", index=False))
     return dists
 
 
 def plot_history(history, dists):
-    if args.plot_history:
-        import matplotlib
-        matplotlib.use("agg")
-        from matplotlib import pyplot as plt
+    """{out}_fitplot.pdf: validation and training loss from the fourth epoch on (locator.py:473-484)."""
+    if not args.plot_history or not len(history.history.get("loss", [])):
+        return
+    import matplotlib
+    matplotlib.use("agg")
+    from matplotlib import pyplot as plt
+    with plt.rc_context({"font.size": 7}):
         fig = plt.figure(figsize=(4, 1.5), dpi=200)
-        plt.rcParams.update({"font.size": 7})
-        ax1 = fig.add_axes([0, 0, 0.4, 1])
-        ax1.plot(history.history["val_loss"][3:], "-", color="black", lw=0.5)
-        ax1.set_xlabel("Validation Loss")
-        ax2 = fig.add_axes([0.55, 0, 0.4, 1])
-        ax2.plot(history.history["loss"][3:], "-", color="black", lw=0.5)
-        ax2.set_xlabel("Training Loss")
+        for left, key, label in ((0.0, "val_loss", "Validation Loss"), (0.55, "loss", "Training Loss")):
+            ax = fig.add_axes([left, 0, 0.4, 1])
+            ax.plot(history.history[key][3:], "-", color="black", lw=0.5)
+            ax.set_xlabel(label)
         fig.savefig(args.out + "_fitplot.pdf", bbox_inches="tight")
         plt.close(fig)
 
@@ -381,14 +435,18 @@ def _fit_unit(unit, device="cuda:0"):
     traingen, testgen = DeviceRows(X, 0, ntr, K), DeviceRows(X, ntr, nva, K)
     predgen = DeviceRows(X, ntr + nva, npr, K)
     model = load_network(traingen, args.dropout_prop, replicate=unit["replicate"], device=device)
-    callbacks = load_callbacks(unit["boot"])
-    history, model = train_network(model, traingen, testgen, unit["trainlocs"], unit["testlocs"], callbacks,
-                                   unit["boot"])
+    # every file of this unit hangs off the unit's own stem (for a window: {out}_{start}-{end}; the reference swaps
+    # args.out only after training, so its --keep_weights file is overwritten by every window)
     original_out = args.out
     args.out = unit["out"]
-    dists = predict_locs(model, predgen, unit["sdlong"], unit["meanlong"], unit["sdlat"], unit["meanlat"],
-                         unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
-    args.out = original_out
+    try:
+        callbacks = load_callbacks(unit["boot"])
+        history, model = train_network(model, traingen, testgen, unit["trainlocs"], unit["testlocs"], callbacks,
+                                       unit["boot"])
+        dists = predict_locs(model, predgen, unit["sdlong"], unit["meanlong"], unit["sdlat"], unit["meanlat"],
+                             unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
+    finally:
+        args.out = original_out
     return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t1}
 
 
@@ -513,24 +571,24 @@ def main(argv=None):
         (meanlong, sdlong, meanlat, sdlat, ac, train, test, traingen, testgen, trainlocs, testlocs, pred,
          predgen) = state
 
+    failed = 0
     if args.windows:
         units = _window_units(samples)
         results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu)
-        for r in results:                       # fitplot is overwritten per window in the reference
+        for r in results:
             if "error" in r:
                 print(f"{r['name']}: FAILED: {r['error']}")
             else:
                 print(f"{r['name']}: run time {r['seconds'] / 60:.2f} minutes")
+        failed = sum("error" in r for r in results)
         results = [r for r in results if "error" not in r]
-        if results and args.plot_history:
+        if results:                             # fitplot is overwritten per window in the reference: last one wins
             plot_history(_H(results[-1]["history"]), results[-1]["dists"])
     elif not args.bootstrap and not args.jacknife:
         unit = dict(name="single", replicate=0, boot=0, out=args.out, traingen=traingen, testgen=testgen,
                     predgen=predgen, trainlocs=trainlocs, testlocs=testlocs, pred=pred, samples=samples,
                     sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, args=args)
         r = _fit_unit(unit)
-        if "error" in r:
-            raise SystemExit(r["error"])
         plot_history(_H(r["history"]), r["dists"])
     elif args.bootstrap:
         units = _bootstrap_units(traingen.shape[1])
@@ -539,33 +597,70 @@ def main(argv=None):
                       samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, out=args.out)
         results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, shared=shared,
                                        fits_per_gpu=args.fits_per_gpu)
+        failed = sum("error" in r for r in results)
         # {out}_history.txt / fitplot are overwritten by every replicate in the reference: last one wins
         results = [r for r in results if "error" not in r]
         if results:
             import pandas as pd
-            pd.DataFrame(results[-1]["history"]).to_csv(args.out + "_history.txt", sep="\t", index=False)
-            if args.plot_history:
-                plot_history(_H(results[-1]["history"]), results[-1]["dists"])
+            last = pd.DataFrame(results[-1]["history"])
+            _write_atomic(args.out + "_history.txt", lambda fh: last.to_csv(fh, sep="\t", index=False))
+            plot_history(_H(results[-1]["history"]), results[-1]["dists"])
     elif args.jacknife:
-        boot = "FULL"
-        model = load_network(traingen, args.dropout_prop)
-        callbacks = load_callbacks(boot)
-        start = time.time()
-        history, model = train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot)
-        dists = predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen,
-                             history, boot)
-        plot_history(history, dists)
-        print("run time " + str((time.time() - start) / 60) + " minutes")
-        print("starting jacknife resampling")
-        af = ac.sum(axis=1) / (ac.shape[1] * 2)
-        for boot in range(args.nboots):
-            pg = copy.deepcopy(np.asarray(predgen))
-            sites_to_remove = np.random.choice(pg.shape[1], int(pg.shape[1] * args.jacknife_prop), replace=False)
-            for i in sites_to_remove:
-                pg[:, i] = np.random.binomial(2, af[i], pg.shape[0])
-            predict_locs(model, pg, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
-                         boot, verbose=False)
+        _jacknife(ac, traingen, testgen, trainlocs, testlocs, predgen, pred, samples, sdlong, meanlong, sdlat, meanlat)
+    if failed:
+        print(f"{failed} replicate fit(s) FAILED", file=sys.stderr)
+        return 1
     return 0
+
+
+def jacknife_draws(predgen, af, nboots, prop):
+    """The reference's jacknife randomness (locator.py:713-727), replicate after replicate from the global NumPy
+    stream: the sites to redraw (choice without replacement), then for each of them, in that order, one
+    Binomial(2, site frequency) per prediction sample.  The per-site calls of the reference are issued as ONE
+    broadcast call per replicate: the legacy generator fills a broadcast request element by element in row-major
+    order through the same scalar routine, so the stream - and every value - is the same (tests/test_host.py).
+    Returns [(sites, values[n_sites][n_pred])]."""
+    n_pred, K = predgen.shape
+    out = []
+    for _ in range(nboots):
+        sites = np.random.choice(K, int(K * prop), replace=False)
+        vals = np.random.binomial(2, np.asarray(af)[sites][:, None], (len(sites), n_pred)) if len(sites) else \
+            np.zeros((0, n_pred), np.int64)
+        out.append((sites, vals))
+    return out
+
+
+def _jacknife(ac, traingen, testgen, trainlocs, testlocs, predgen, pred, samples, sdlong, meanlong, sdlat, meanlat):
+    """--jacknife (locator.py:683-747): one fit, then nboots re-predictions of the unknown samples with a fraction of
+    their SNPs redrawn from the site frequencies.  The reference predicts replicate by replicate; here the nboots
+    perturbed copies form ONE matrix of nboots x n_pred rows that goes up once and through one many-row predict (the
+    first layer as a large-M GEMM against a weight image converted once)."""
+    boot = "FULL"
+    start = time.time()
+    model = load_network(traingen, args.dropout_prop)
+    history, model = train_network(model, traingen, testgen, trainlocs, testlocs, load_callbacks(boot), boot)
+    dists = predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
+                         boot)
+    plot_history(history, dists)
+    print("run time " + str((time.time() - start) / 60) + " minutes")
+    print("starting jacknife resampling")
+    base = np.ascontiguousarray(np.asarray(predgen)).astype(np.uint8, copy=False)
+    n_pred = base.shape[0]
+    if n_pred == 0 or args.nboots < 1:
+        return
+    af = ac.sum(axis=1) / (ac.shape[1] * 2)
+    draws = jacknife_draws(base, af, args.nboots, args.jacknife_prop)
+    ids = np.asarray(samples)[pred]
+    group = max(1, int(2e9 // max(1, base.size)))          # replicates per upload: at most ~2 GB of host staging
+    for b0 in range(0, args.nboots, group):
+        nb = min(group, args.nboots - b0)
+        stacked = np.tile(base, (nb, 1))
+        for b in range(nb):
+            sites, vals = draws[b0 + b]
+            stacked[b * n_pred:(b + 1) * n_pred, sites] = vals.T
+        xy = _to_map_units(model.predict(stacked), sdlong, meanlong, sdlat, meanlat)
+        for b in range(nb):
+            write_predlocs(_predlocs_path(b0 + b), xy[b * n_pred:(b + 1) * n_pred], ids)
 
 
 class _H:

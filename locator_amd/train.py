@@ -20,9 +20,10 @@ class Callbacks:
     """ModelCheckpoint(best only) -> EarlyStopping -> ReduceLROnPlateau on val_loss, in that order
     (locator.py:362).  All comparisons are strict '<' with min_delta 0 (locator.py:349-361)."""
 
-    def __init__(self, patience=100, lr0=1e-3):
+    def __init__(self, patience=100, lr0=1e-3, lr_patience=None, lr_factor=0.5):
         self.patience = int(patience)
-        self.lr_patience = int(patience / 6)          # locator.py:354
+        self.lr_patience = int(patience / 6) if lr_patience is None else int(lr_patience)     # locator.py:354
+        self.lr_factor = float(lr_factor)
         self.lr = float(np.float32(lr0))              # Keras keeps the LR in an fp32 variable
         self.ck_best = np.inf
         self.es_best = np.inf
@@ -46,7 +47,7 @@ class Callbacks:
         else:
             self.rl_wait += 1
             if self.rl_wait >= self.lr_patience:
-                self.lr = float(np.float32(max(np.float32(self.lr) * np.float32(0.5), 0.0)))
+                self.lr = float(np.float32(max(np.float32(self.lr) * np.float32(self.lr_factor), 0.0)))
                 self.rl_wait = 0
         return save, stop, lr_logged
 
@@ -148,12 +149,14 @@ class EpochRunner:
         return self.finish_epoch()
 
 
-def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, perm_fn=None,
-        use_graph=True, verbose=0, log=print):
+def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
+        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print):
     """train_network (locator.py:365-394): fit with checkpoint / early-stop / LR-plateau callbacks, then
-    reload the best weights.  Returns a History."""
+    reload the best weights.  Returns a History.  lr_patience None = int(patience / 6) (locator.py:354)."""
+    if len(val_rows) == 0:
+        raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
     runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph)
-    cb = Callbacks(patience, 1e-3)
+    cb = Callbacks(patience, 1e-3, lr_patience, lr_factor)
     hist = History()
     rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))
     if perm_fn is None:
@@ -178,5 +181,9 @@ def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000
                 f"learning_rate: {lr_logged:.4e}")
         if stop:
             break
+    if net.best is None:
+        # val_loss was never finite (diverged fit): the reference dies here too, load_weights finds no checkpoint file
+        raise RuntimeError(f"training produced no checkpoint: val_loss was never finite in {len(hist.history['loss'])} "
+                           f"epochs (last loss {hist.history['loss'][-1]}, last val_loss {hist.history['val_loss'][-1]})")
     net.restore_best()
     return hist

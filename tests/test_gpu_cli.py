@@ -126,3 +126,72 @@ def test_batch_size_64_and_rejected_batch_sizes(tmp_path, capsys):
     with pytest.raises(ValueError, match=r"1\.\.128"):
         _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", str(tmp_path / "b129"), "--seed", "1",
               "--max_epochs", "2", "--keras_verbose", "0", "--batch_size", "129"])
+
+
+def test_jacknife_is_one_batched_predict_and_matches_the_oracle_on_the_same_perturbed_matrices(tmp_path, monkeypatch):
+    """--jacknife: the nboots perturbed copies of the prediction genotypes go through ONE many-row predict (here
+    40 x 50 = 2000 rows: the image + GEMM first layer).  The draws are recorded as the CLI makes them, the perturbed
+    matrices rebuilt on the host, and every {out}_boot{b}_predlocs.txt compared with oracle.predict on the weights
+    the run kept (2e-5 on z-scored outputs, scaled to map units)."""
+    from oracle import locator_oracle as O
+    v = G.read_vcf(VCF)
+    ac = G.filter_snps(v["calldata/GT"][:6000], 2, verbose=False)[:1500]
+    mat = str(tmp_path / "m.txt")
+    df = pd.DataFrame(ac.T, columns=[f"s{i}" for i in range(ac.shape[0])])
+    df.insert(0, "sampleID", v["samples"])
+    df.to_csv(mat, sep="\t", index=False)
+    recorded = {}
+    real_draws, real_predict = L.jacknife_draws, L.Model.predict
+
+    def spy_draws(predgen, af, nboots, prop):
+        recorded["predgen"] = np.array(predgen)
+        recorded["draws"] = real_draws(predgen, af, nboots, prop)
+        return recorded["draws"]
+
+    def spy_predict(self, gen):
+        recorded.setdefault("rows", []).append(gen.shape[0])
+        return real_predict(self, gen)
+    monkeypatch.setattr(L, "jacknife_draws", spy_draws)
+    monkeypatch.setattr(L.Model, "predict", spy_predict)
+    out = str(tmp_path / "j")
+    nboots = 40
+    _run(["--matrix", mat, "--sample_data", SAMPLES, "--out", out, "--seed", "7", "--jacknife", "--nboots", str(nboots),
+          "--max_epochs", "3", "--patience", "3", "--keras_verbose", "0", "--keep_weights", "--min_mac", "1",
+          "--plot_history", ""])
+    assert recorded["rows"][-1] == nboots * 50                  # one predict for all replicates
+    p = O.cast_params(L.read_weights(out + "_bootFULL.weights.npz"), np.float64)
+    sd = pd.read_csv(SAMPLES, sep="\t")
+    mx, sx, my, sy = sd["x"].mean(), sd["x"].std(ddof=0), sd["y"].mean(), sd["y"].std(ddof=0)
+    for b in (0, 17, nboots - 1):
+        sites, vals = recorded["draws"][b]
+        pg = recorded["predgen"].copy()
+        pg[:, sites] = vals.T
+        z = O.predict(p, pg)
+        got = pd.read_csv(f"{out}_boot{b}_predlocs.txt")
+        assert np.abs(got["x"].to_numpy() - (z[:, 0] * sx + mx)).max() < 2e-5 * sx + 1e-9
+        assert np.abs(got["y"].to_numpy() - (z[:, 1] * sy + my)).max() < 2e-5 * sy + 1e-9
+
+
+def test_load_weights_predicts_without_training_and_edited_callbacks_change_the_fit(tmp_path, monkeypatch):
+    """--keep_weights then --load_weights: the second run trains nothing and writes the same predictions.  And the
+    dicts load_callbacks returns are what train_network consumes: a shorter earlystop patience ends the fit earlier."""
+    a = str(tmp_path / "a")
+    common = ["--vcf", VCF, "--sample_data", SAMPLES, "--seed", "12345", "--keras_verbose", "0", "--plot_history", ""]
+    _run(common + ["--out", a, "--max_epochs", "40", "--patience", "25", "--keep_weights"])
+    n_a = len(pd.read_csv(a + "_history.txt", sep="\t"))
+    b = str(tmp_path / "b")
+    _run(common + ["--out", b, "--load_weights", a + ".weights.npz"])
+    assert open(a + "_predlocs.txt").read() == open(b + "_predlocs.txt").read()
+    assert not os.path.exists(b + "_history.txt")
+    real = L.load_callbacks
+
+    def short_patience(boot):
+        ck, es, rl = real(boot)
+        es["patience"] = 2
+        return ck, es, rl
+    monkeypatch.setattr(L, "load_callbacks", short_patience)
+    c = str(tmp_path / "c")
+    _run(common + ["--out", c, "--max_epochs", "40", "--patience", "25"])
+    n_c = len(pd.read_csv(c + "_history.txt", sep="\t"))
+    h = pd.read_csv(c + "_history.txt", sep="\t")
+    assert n_c < n_a and n_c - 1 - int(h["val_loss"].idxmin()) == 2
