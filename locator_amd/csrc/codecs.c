@@ -1,0 +1,120 @@
+/* Host-side chunk codecs for the zarr reader (locator_amd/genotypes.py): the Blosc-1 container with LZ4 (and zlib)
+ * payloads and byte-shuffle.  The reference reads zarr stores through zarr + numcodecs (locator.py:188-193,
+ * scripts/vcf_to_zarr.py:12: `allel.vcf_to_zarr`, whose default compressor is Blosc(cname="lz4", clevel=5,
+ * shuffle=1)); neither library is available here, so the published formats are restated:
+ *   Blosc-1 chunk: 16-byte header {version, versionlz, flags, typesize, nbytes u32, blocksize u32, cbytes u32}
+ *     flags: 0x01 byte-shuffle, 0x02 memcpy'ed, 0x04 bit-shuffle, 0x10 do-not-split, bits 5-7 codec
+ *     (0 blosclz, 1 lz4/lz4hc, 2 snappy, 3 zlib, 4 zstd); then, unless memcpy'ed, nblocks int32 block offsets; every
+ *     block is 1 stream or (split) `typesize` streams, each {int32 csize, data}; csize == stream size means stored.
+ *   LZ4 block: sequences of {token, [literal length bytes], literals, offset u16, [match length bytes]}.
+ * Pinned against the reference's own Blosc/LZ4 chunks (locator_py/map.zarr, tests/golden/blosc_*): tests/test_host.py.
+ * Plain C, no device code; built into locator_amd/libloc_codecs.so by the same Makefile. */
+#include <stdint.h>
+#include <string.h>
+#include <zlib.h>
+
+static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+/* returns the number of bytes written to dst, or -1 on malformed input / overflow */
+int64_t loc_lz4_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
+    const uint8_t *ip = src, *iend = src + src_len;
+    uint8_t *op = dst, *oend = dst + dst_cap;
+    while (ip < iend) {
+        const unsigned token = *ip++;
+        int64_t ll = token >> 4;
+        if (ll == 15) {
+            unsigned b;
+            do { if (ip >= iend) return -1; b = *ip++; ll += b; } while (b == 255);
+        }
+        if (ll > iend - ip || ll > oend - op) return -1;
+        memcpy(op, ip, (size_t)ll);
+        ip += ll; op += ll;
+        if (ip >= iend) break;                    /* the last sequence is literals only */
+        if (iend - ip < 2) return -1;
+        const int64_t off = ip[0] | (ip[1] << 8);
+        ip += 2;
+        if (off == 0 || off > op - dst) return -1;
+        int64_t ml = (token & 15) + 4;
+        if ((token & 15) == 15) {
+            unsigned b;
+            do { if (ip >= iend) return -1; b = *ip++; ml += b; } while (b == 255);
+        }
+        if (ml > oend - op) return -1;
+        const uint8_t* m = op - off;
+        if (off >= ml) { memcpy(op, m, (size_t)ml); op += ml; }
+        else { for (int64_t i = 0; i < ml; ++i) op[i] = m[i]; op += ml; }      /* overlapping run */
+    }
+    return op - dst;
+}
+
+static int64_t inflate_to(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
+    uLongf n = (uLongf)dst_cap;
+    if (uncompress(dst, &n, src, (uLong)src_len) != Z_OK) return -1;
+    return (int64_t)n;
+}
+
+/* Decode one Blosc-1 chunk.  split_mode: 0 = follow the header, 1 = force split streams, 2 = force unsplit (older
+ * writers decide the split without recording it; the caller retries).  tmp: at least `blocksize` bytes (see
+ * loc_blosc1_info).  Returns the decompressed byte count (== header nbytes) or a negative error:
+ *   -1 malformed, -2 unsupported codec, -3 unsupported filter (bit-shuffle), -4 output buffer too small. */
+int64_t loc_blosc1_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap, uint8_t* tmp,
+                              int split_mode) {
+    if (src_len < 16) return -1;
+    const unsigned flags = src[2];
+    const int64_t typesize = src[3] ? src[3] : 1;
+    const int64_t nbytes = rd32(src + 4), blocksize = rd32(src + 8), cbytes = rd32(src + 12);
+    if (cbytes > src_len || nbytes > dst_cap) return nbytes > dst_cap ? -4 : -1;
+    if (nbytes == 0) return 0;
+    if (flags & 0x02) {                                                   /* stored */
+        if (16 + nbytes > src_len) return -1;
+        memcpy(dst, src + 16, (size_t)nbytes);
+        return nbytes;
+    }
+    if (flags & 0x04) return -3;
+    const unsigned codec = flags >> 5;
+    if (codec != 1 && codec != 3) return -2;
+    if (blocksize <= 0) return -1;
+    const int shuffle = (flags & 0x01) && typesize > 1;
+    const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    if (16 + 4 * nblocks > src_len) return -1;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int64_t bsize = (b == nblocks - 1 && nbytes % blocksize) ? nbytes % blocksize : blocksize;
+        const int leftover = bsize != blocksize;
+        int split = typesize > 1 && typesize <= 16 && (blocksize / typesize) >= 128 && !leftover && !(flags & 0x10);
+        if (split_mode == 1) split = typesize > 1 && !leftover && bsize % typesize == 0;
+        if (split_mode == 2) split = 0;
+        const int64_t nstreams = split ? typesize : 1, ssize = bsize / nstreams;
+        int64_t pos = (int64_t)(int32_t)rd32(src + 16 + 4 * b);
+        uint8_t* out = shuffle ? tmp : dst + b * blocksize;
+        for (int64_t s = 0; s < nstreams; ++s) {
+            if (pos < 0 || pos + 4 > src_len) return -1;
+            const int64_t cs = (int64_t)(int32_t)rd32(src + pos);
+            pos += 4;
+            if (cs < 0 || pos + cs > src_len) return -1;
+            if (cs == ssize) memcpy(out + s * ssize, src + pos, (size_t)ssize);
+            else {
+                const int64_t got = codec == 1 ? loc_lz4_decompress(src + pos, cs, out + s * ssize, ssize)
+                                                : inflate_to(src + pos, cs, out + s * ssize, ssize);
+                if (got != ssize) return -1;
+            }
+            pos += cs;
+        }
+        if (shuffle) {                 /* byte j of element i sits at tmp[j*nelem + i]; trailing bytes are copied */
+            uint8_t* o = dst + b * blocksize;
+            const int64_t nelem = bsize / typesize;
+            for (int64_t j = 0; j < typesize; ++j) {
+                const uint8_t* in = tmp + j * nelem;
+                for (int64_t i = 0; i < nelem; ++i) o[i * typesize + j] = in[i];
+            }
+            memcpy(o + nelem * typesize, tmp + nelem * typesize, (size_t)(bsize - nelem * typesize));
+        }
+    }
+    return nbytes;
+}
+
+/* header fields without decoding: out[0..4] = {nbytes, blocksize, cbytes, typesize, flags}; 0 ok, -1 too short */
+int loc_blosc1_info(const uint8_t* src, int64_t src_len, int64_t* out) {
+    if (src_len < 16) return -1;
+    out[0] = rd32(src + 4); out[1] = rd32(src + 8); out[2] = rd32(src + 12); out[3] = src[3]; out[4] = src[2];
+    return 0;
+}

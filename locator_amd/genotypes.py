@@ -88,10 +88,141 @@ def read_vcf(path):
 
 
 # ------------------------------------------------------------------ zarr v2 directory store
+_CODECS = None
+
+
+def _codecs():
+    """libloc_codecs.so (locator_amd/csrc/codecs.c): the Blosc-1 / LZ4 chunk decoder, built with the HIP library."""
+    global _CODECS
+    if _CODECS is None:
+        import ctypes as C
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libloc_codecs.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `make -C locator_amd/csrc` (blosc-compressed zarr "
+                               "chunks cannot be read without it)")
+        lib = C.CDLL(path)
+        lib.loc_blosc1_decompress.restype = C.c_int64
+        lib.loc_blosc1_decompress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib.loc_blosc1_info.restype = C.c_int
+        lib.loc_blosc1_info.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.loc_lz4_decompress.restype = C.c_int64
+        lib.loc_lz4_decompress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        _CODECS = lib
+    return _CODECS
+
+
+def blosc_decompress(raw):
+    """One Blosc-1 chunk (what numcodecs.Blosc / `allel.vcf_to_zarr` write by default: LZ4, byte-shuffle) -> bytes.
+    Codecs: lz4 / lz4hc, zlib, stored; filters: byte-shuffle.  zstd / blosclz / bit-shuffle raise."""
+    import ctypes as C
+    lib = _codecs()
+    info = (C.c_int64 * 5)()
+    if lib.loc_blosc1_info(raw, len(raw), info) != 0:
+        raise ValueError("blosc chunk shorter than its header")
+    nbytes, blocksize = int(info[0]), int(info[1])
+    out = np.empty(nbytes, np.uint8)
+    tmp = np.empty(max(blocksize, 1), np.uint8)
+    for mode in (0, 1, 2):            # as the header says; then the two split conventions of writers that do not say
+        r = lib.loc_blosc1_decompress(raw, len(raw), out.ctypes.data, nbytes, tmp.ctypes.data, mode)
+        if r == nbytes:
+            return out.tobytes()
+        if r in (-2, -3):
+            what = "codec (supported: lz4, zlib, stored)" if r == -2 else "filter bit-shuffle"
+            raise ValueError(f"blosc chunk uses an unsupported {what}; re-encode the store with "
+                             "Blosc(cname='lz4') or zlib")
+    raise ValueError("malformed blosc chunk")
+
+
+def _lz4_compress_block(data):
+    """Greedy LZ4 block encoder (hash of 4-byte windows, one candidate per hash).  Only used to WRITE small
+    synthetic / test stores in the format real tools produce; the reader side is csrc/codecs.c."""
+    n = len(data)
+    out = bytearray()
+    table = {}
+    i = anchor = 0
+    limit = n - 12                              # format rule: the last match starts >= 12 bytes before the end
+    while i < limit:
+        key = data[i:i + 4]
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand <= 65535:
+            m = 4
+            end = n - 5                         # and the last 5 bytes are literals
+            while i + m < end and data[cand + m] == data[i + m]:
+                m += 1
+            lit = i - anchor
+            token = (min(lit, 15) << 4) | min(m - 4, 15)
+            out.append(token)
+            if lit >= 15:
+                r = lit - 15
+                while r >= 255:
+                    out.append(255)
+                    r -= 255
+                out.append(r)
+            out += data[anchor:i]
+            out += (i - cand).to_bytes(2, "little")
+            if m - 4 >= 15:
+                r = m - 4 - 15
+                while r >= 255:
+                    out.append(255)
+                    r -= 255
+                out.append(r)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    lit = n - anchor
+    out.append(min(lit, 15) << 4)
+    if lit >= 15:
+        r = lit - 15
+        while r >= 255:
+            out.append(255)
+            r -= 255
+        out.append(r)
+    out += data[anchor:]
+    return bytes(out)
+
+
+def blosc_compress(raw, typesize=1, shuffle=True, blocksize=1 << 16):
+    """Blosc-1 chunk with LZ4 streams and byte-shuffle, laid out as c-blosc writes it (16-byte header, block offsets,
+    per-stream {int32 size, data}, split into `typesize` streams when the block is large enough)."""
+    raw = bytes(raw)
+    nbytes = len(raw)
+    typesize = max(1, int(typesize))
+    blocksize = max(typesize, min(blocksize, nbytes) // typesize * typesize) if nbytes else typesize
+    do_shuffle = shuffle and typesize > 1
+    flags = (1 << 5) | (1 if do_shuffle else 0)
+    nblocks = (nbytes + blocksize - 1) // blocksize if nbytes else 0
+    body, starts = bytearray(), []
+    pos = 16 + 4 * nblocks
+    for b in range(nblocks):
+        blk = raw[b * blocksize:(b + 1) * blocksize]
+        leftover = len(blk) != blocksize
+        if do_shuffle:
+            ne = len(blk) // typesize
+            arr = np.frombuffer(blk[:ne * typesize], np.uint8).reshape(ne, typesize).T.tobytes() + blk[ne * typesize:]
+        else:
+            arr = blk
+        split = typesize > 1 and typesize <= 16 and blocksize // typesize >= 128 and not leftover
+        ns = typesize if split else 1
+        ss = len(arr) // ns
+        starts.append(pos)
+        for k in range(ns):
+            stream = arr[k * ss:(k + 1) * ss]
+            comp = _lz4_compress_block(stream)
+            if len(comp) >= len(stream):
+                comp = stream                                    # stored
+            body += len(comp).to_bytes(4, "little") + comp
+            pos += 4 + len(comp)
+    head = bytes([2, 1, flags, typesize]) + nbytes.to_bytes(4, "little") + blocksize.to_bytes(4, "little") + \
+        (16 + 4 * nblocks + len(body)).to_bytes(4, "little")
+    return head + b"".join(x.to_bytes(4, "little") for x in starts) + bytes(body)
+
+
 class ZarrArray:
-    """Read-only zarr-v2 array in a directory store.  Compressors: none, zlib, gzip.  (Real
-    `allel.vcf_to_zarr` output defaults to blosc, which needs numcodecs: re-encode such stores with
-    `compressor=None` or zlib; see INTEGRATION.md.)  Filters: vlen-utf8 (object string arrays)."""
+    """Read-only zarr-v2 array in a directory store.  Compressors: none, zlib, gzip and blosc (the default of
+    `allel.vcf_to_zarr`, scripts/vcf_to_zarr.py:12: Blosc-1 container with LZ4 / zlib payloads and byte-shuffle,
+    decoded by csrc/codecs.c).  Filters: vlen-utf8 (object string arrays)."""
 
     def __init__(self, path):
         self.path = path
@@ -109,15 +240,17 @@ class ZarrArray:
         self.sep = meta.get("dimension_separator", ".")
         self.ndim = len(self.shape)
         self.vlen_utf8 = any(f.get("id") == "vlen-utf8" for f in self.filters)
-        if self.compressor is not None and self.compressor.get("id") not in ("zlib", "gzip"):
+        if self.compressor is not None and self.compressor.get("id") not in ("zlib", "gzip", "blosc"):
             raise ValueError(f"{path}: compressor {self.compressor.get('id')!r} is not supported here "
-                             "(supported: null, zlib, gzip)")
+                             "(supported: null, zlib, gzip, blosc)")
 
     def __len__(self):
         return self.shape[0]
 
     def _decode(self, raw, cshape):
-        if self.compressor is not None:
+        if self.compressor is not None and self.compressor.get("id") == "blosc":
+            raw = blosc_decompress(raw)
+        elif self.compressor is not None:
             raw = zlib.decompress(raw, 15 + 32)        # auto-detect zlib / gzip framing
         if self.vlen_utf8:
             n = struct.unpack_from("<I", raw, 0)[0]
@@ -204,12 +337,15 @@ def open_group(path, mode="r"):
 
 
 def write_zarr_array(path, arr, chunks, compressor=None):
-    """Minimal zarr-v2 writer (uncompressed or zlib) used to build synthetic stores (config 4)."""
+    """Minimal zarr-v2 writer (uncompressed, zlib, or "blosc" = Blosc-1 / LZ4 / byte-shuffle as `allel.vcf_to_zarr`
+    writes by default) used to build synthetic stores (config 4) and test fixtures."""
     arr = np.asarray(arr)
     os.makedirs(path, exist_ok=True)
     chunks = tuple(int(min(c, s)) if s else 1 for c, s in zip(chunks, arr.shape))
     meta = {"zarr_format": 2, "shape": list(arr.shape), "chunks": list(chunks), "dtype": arr.dtype.str,
-            "compressor": ({"id": "zlib", "level": 1} if compressor == "zlib" else None), "fill_value": 0,
+            "compressor": ({"id": "zlib", "level": 1} if compressor == "zlib" else
+                           {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+                           if compressor == "blosc" else None), "fill_value": 0,
             "order": "C", "filters": None}
     with open(os.path.join(path, ".zarray"), "w") as fh:
         json.dump(meta, fh)
@@ -222,6 +358,8 @@ def write_zarr_array(path, arr, chunks, compressor=None):
         raw = block.tobytes()
         if compressor == "zlib":
             raw = zlib.compress(raw, 1)
+        elif compressor == "blosc":
+            raw = blosc_compress(raw, arr.dtype.itemsize)
         with open(os.path.join(path, ".".join(map(str, idx))), "wb") as fh:
             fh.write(raw)
 

@@ -129,21 +129,19 @@ def _write_atomic(path, writer, mode="w"):
 
 # ------------------------------------------------------------------ ingest (locator.py:187-308)
 def load_genotypes():
+    """(variants, samples, 2) int8 calls and the sample IDs from whichever of --zarr / --vcf / --matrix was given
+    (locator.py:187-228); the readers live in genotypes.py (no scikit-allel / zarr dependency)."""
     if args.zarr is not None:
         print("reading zarr")
         callset = G.open_group(args.zarr, mode="r")
-        genotypes = np.asarray(callset["calldata/GT"][:], dtype=np.int8)
-        samples = np.asarray(callset["samples"][:])
-    elif args.vcf is not None:
+        return np.asarray(callset["calldata/GT"][:], dtype=np.int8), np.asarray(callset["samples"][:])
+    if args.vcf is not None:
         print("reading VCF")
         vcf = G.read_vcf(args.vcf)
-        genotypes = vcf["calldata/GT"]
-        samples = vcf["samples"]
-    elif args.matrix is not None:
-        genotypes, samples = G.read_matrix(args.matrix)
-    else:
-        raise SystemExit("one of --zarr, --vcf or --matrix is required")
-    return genotypes, samples
+        return vcf["calldata/GT"], vcf["samples"]
+    if args.matrix is not None:
+        return G.read_matrix(args.matrix)
+    raise SystemExit("one of --zarr, --vcf or --matrix is required")
 
 
 def sort_samples(samples, genotypes):
@@ -172,12 +170,10 @@ def filter_snps(genotypes):
 
 
 def normalize_locs(locs):
-    meanlong = np.nanmean(locs[:, 0])
-    sdlong = np.nanstd(locs[:, 0])
-    meanlat = np.nanmean(locs[:, 1])
-    sdlat = np.nanstd(locs[:, 1])
-    locs = np.stack([(locs[:, 0] - meanlong) / sdlong, (locs[:, 1] - meanlat) / sdlat], axis=1)
-    return meanlong, sdlong, meanlat, sdlat, locs
+    """z-score each coordinate over the located samples (locator.py:284-292; NaN rows stay NaN)."""
+    (meanlong, sdlong), (meanlat, sdlat) = [(np.nanmean(col), np.nanstd(col)) for col in (locs[:, 0], locs[:, 1])]
+    scaled = np.column_stack([(locs[:, 0] - meanlong) / sdlong, (locs[:, 1] - meanlat) / sdlat])
+    return meanlong, sdlong, meanlat, sdlat, scaled
 
 
 def split_indices(locs, train_split):
@@ -192,13 +188,10 @@ def split_indices(locs, train_split):
 
 
 def split_train_test(ac, locs):
+    """locator.py:295-308: row sets from split_indices, genotypes as sample-major matrices."""
     train, test, pred = split_indices(locs, args.train_split)
-    traingen = np.transpose(ac[:, train])
-    trainlocs = locs[train]
-    testgen = np.transpose(ac[:, test])
-    testlocs = locs[test]
-    predgen = np.transpose(ac[:, pred]) if len(pred) else np.zeros((0, ac.shape[0]), ac.dtype)
-    return train, test, traingen, testgen, trainlocs, testlocs, pred, predgen
+    rows = lambda idx: ac[:, idx].T if len(idx) else np.zeros((0, ac.shape[0]), ac.dtype)
+    return train, test, rows(train), rows(test), locs[train], locs[test], pred, rows(pred)
 
 
 # ------------------------------------------------------------------ model (locator.py:311-470)
@@ -382,8 +375,8 @@ def predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pre
         print(f"R2(x)={r2[0]}\nR2(y)={r2[1]}\nmean validation error {np.mean(dists)}\n"
               f"median validation error {np.median(dists)}\n")
     if len(history.history.get("loss", [])):
-        hist = pd.DataFrame(history.history)
-        _write_atomic(args.out + "_history.txt", lambda fh: hist.to_csv(fh, sep="\t", index=False))
+        table = pd.DataFrame(history.history)
+        _write_atomic(args.out + "_history.txt", lambda fh: table.to_csv(fh, sep="\t", index=False))
     return dists
 
 
@@ -395,7 +388,7 @@ def plot_history(history, dists):
     matplotlib.use("agg")
     from matplotlib import pyplot as plt
     with plt.rc_context({"font.size": 7}):
-        fig = plt.figure(figsize=(4, 1.5), dpi=200)
+        fig = plt.figure(dpi=200, figsize=(4, 1.5))
         for left, key, label in ((0.0, "val_loss", "Validation Loss"), (0.55, "loss", "Training Loss")):
             ax = fig.add_axes([left, 0, 0.4, 1])
             ax.plot(history.history[key][3:], "-", color="black", lw=0.5)
@@ -417,7 +410,7 @@ def _fit_unit(unit, device="cuda:0"):
     global args
     from .net import gather_columns, upload_genotypes
     args = unit["args"]
-    t1 = time.time()
+    t_unit = time.time()
     if "window" in unit:
         _load_window(unit)
     tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
@@ -447,22 +440,20 @@ def _fit_unit(unit, device="cuda:0"):
                              unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
     finally:
         args.out = original_out
-    return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t1}
+    return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t_unit}
 
 
 def _window_bounds():
-    callset = G.open_group(args.zarr, mode="r")
-    positions = np.array(callset["variants/POS"][:])
-    start = int(args.window_start)
-    stop = np.max(positions) if args.window_stop is None else int(args.window_stop)
-    size = int(args.window_size)
-    out = []
-    for i in np.arange(start, stop, size):
-        mask = np.logical_and(positions >= i, positions < i + size)
-        a = np.min(np.argwhere(mask))               # an empty window raises here, as in the reference
-        b = np.max(np.argwhere(mask))
-        out.append((int(i), int(size), int(a), int(b)))
-    return out
+    """(window start, size, first SNP index, last SNP index) for every window of the run (locator.py:519-537)."""
+    positions = np.asarray(G.open_group(args.zarr, mode="r")["variants/POS"][:])
+    first = int(args.window_start)
+    width = int(args.window_size)
+    last = positions.max() if args.window_stop is None else int(args.window_stop)
+    bounds = []
+    for lo in range(first, int(last), width):
+        inside = np.flatnonzero((positions >= lo) & (positions < lo + width))
+        bounds.append((lo, width, int(inside.min()), int(inside.max())))   # an empty window raises, as in the reference
+    return bounds
 
 
 def _window_units(samples, lazy=None):
@@ -635,14 +626,12 @@ def _jacknife(ac, traingen, testgen, trainlocs, testlocs, predgen, pred, samples
     their SNPs redrawn from the site frequencies.  The reference predicts replicate by replicate; here the nboots
     perturbed copies form ONE matrix of nboots x n_pred rows that goes up once and through one many-row predict (the
     first layer as a large-M GEMM against a weight image converted once)."""
-    boot = "FULL"
-    start = time.time()
-    model = load_network(traingen, args.dropout_prop)
-    history, model = train_network(model, traingen, testgen, trainlocs, testlocs, load_callbacks(boot), boot)
-    dists = predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples, testgen, history,
-                         boot)
-    plot_history(history, dists)
-    print("run time " + str((time.time() - start) / 60) + " minutes")
+    t_fit = time.time()
+    history, model = train_network(load_network(traingen, args.dropout_prop), traingen, testgen, trainlocs, testlocs,
+                                   load_callbacks("FULL"), "FULL")
+    plot_history(history, predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pred, samples,
+                                       testgen, history, "FULL"))
+    print("run time " + str((time.time() - t_fit) / 60) + " minutes")
     print("starting jacknife resampling")
     base = np.ascontiguousarray(np.asarray(predgen)).astype(np.uint8, copy=False)
     n_pred = base.shape[0]

@@ -80,3 +80,10 @@ def test_w1s_index_is_a_bijection_and_matches_mfma_layout():
     # a (k-tile, unit-tile) block is one contiguous 1024-float run
     blk = idx[32:64, 32:64]
     assert blk.min() == (1 * 2 + 1) * 1024 and blk.max() == blk.min() + 1023
+
+
+def test_codecs_library_loads_and_exports_its_entry_points(repo_root):
+    """libloc_codecs.so (csrc/codecs.c, host-side Blosc-1 / LZ4 chunk decoder of the zarr reader)."""
+    lib = C.CDLL(os.path.join(repo_root, "locator_amd", "libloc_codecs.so"))
+    for name in ("loc_lz4_decompress", "loc_blosc1_decompress", "loc_blosc1_info"):
+        assert hasattr(lib, name), name

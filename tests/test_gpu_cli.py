@@ -73,8 +73,9 @@ def test_bootstrap_outputs_and_run_to_run_determinism(tmp_path):
 def test_windows_on_zarr_with_reference_file_naming(tmp_path):
     v = G.read_vcf(VCF)
     store = str(tmp_path / "fix.zarr")
+    # blosc / lz4 / shuffle chunks: what `allel.vcf_to_zarr` (scripts/vcf_to_zarr.py:12) writes by default
     G.write_callset_zarr(store, v["calldata/GT"], v["variants/POS"], v["samples"], chunk_variants=4096,
-                         compressor="zlib")
+                         compressor="blosc")
     out = str(tmp_path / "w")
     _run(["--zarr", store, "--sample_data", SAMPLES, "--out", out, "--seed", "12345", "--windows",
           "--window_size", "1250000", "--max_epochs", "3", "--patience", "3", "--keras_verbose", "0"])

@@ -409,3 +409,60 @@ def test_callbacks_configuration_is_what_the_fit_consumes():
     assert run(patience=100, lr_patience=2)[1][4] == float(np.float32(5e-4))          # halved after 2 bad epochs
     assert run(patience=100, lr_patience=2, lr_factor=0.1)[1][4] == float(np.float32(1e-3) * np.float32(0.1))
     assert run(patience=12)[1][-1] == float(np.float32(1.25e-4)) and Callbacks(patience=12).lr_patience == 2   # int(12 / 6)
+
+
+# ------------------------------------------------------------------ blosc-compressed zarr
+def test_blosc_decoder_on_the_references_own_chunks(repo_root):
+    """locator_py/map.zarr in the reference holds 2,128 arrays written by zarr + numcodecs with the default
+    compressor (Blosc-1, cname lz4, shuffle 1) - the same format `allel.vcf_to_zarr` writes for genotype stores
+    (scripts/vcf_to_zarr.py:12).  Three of its chunks are fixtures here (flags 0x21 split LZ4 streams + byte-shuffle,
+    0x31 unsplit, 0x33 stored).  They are country outlines: the decoded float64 arrays must be finite longitudes /
+    latitudes and closed rings (first vertex == last vertex), which no wrong decoding produces."""
+    root = os.path.join(repo_root, "tests", "golden", "blosc_map_zarr")
+    seen = set()
+    for name in sorted(os.listdir(root)):
+        a = G.ZarrArray(os.path.join(root, name))
+        raw = open(os.path.join(root, name, "0.0"), "rb").read()
+        seen.add(raw[2])
+        xy = a[:]
+        assert xy.shape == a.shape and xy.dtype == np.float64 and xy.shape[0] == 2
+        assert np.isfinite(xy).all() and np.abs(xy[0]).max() <= 180 and np.abs(xy[1]).max() <= 90
+        assert np.array_equal(xy[:, 0], xy[:, -1]) and np.ptp(xy[0]) > 0
+    assert seen == {0x21, 0x31, 0x33}
+    afg = G.ZarrArray(os.path.join(root, "Afghanistan"))[:]
+    assert 60 < afg[0].min() < afg[0].max() < 75.5 and 29 < afg[1].min() < afg[1].max() < 39     # where Afghanistan is
+
+
+def test_blosc_zarr_store_round_trip_and_unsupported_codecs(tmp_path):
+    """A genotype store written the way `allel.vcf_to_zarr` writes it (blosc / lz4 / shuffle on calldata/GT int8 and
+    variants/POS int32) reads back identically through the C decoder, sliced like the window loop slices it; truncated
+    chunks and the codecs that are not built (zstd, bit-shuffle) fail loudly."""
+    rng = np.random.default_rng(8)
+    gt = (rng.random((3000, 41, 2)) < 0.2).astype(np.int8)
+    gt[rng.random(gt.shape) < 0.01] = -1
+    pos = np.sort(rng.choice(10_000_000, 3000, replace=False)).astype(np.int32)
+    samples = np.array([f"s{i}" for i in range(41)])
+    store = str(tmp_path / "b.zarr")
+    G.write_callset_zarr(store, gt, pos, samples, chunk_variants=1024, compressor="blosc")
+    meta = json.load(open(os.path.join(store, "calldata", "GT", ".zarray")))
+    assert meta["compressor"]["id"] == "blosc" and meta["compressor"]["cname"] == "lz4"
+    cs = G.open_group(store, mode="r")
+    assert np.array_equal(cs["calldata/GT"][:], gt) and np.array_equal(cs["variants/POS"][:], pos)
+    assert np.array_equal(cs["calldata/GT"][1000:2100, :, :], gt[1000:2100])
+    assert list(cs["samples"][:]) == list(samples)
+    raw = open(os.path.join(store, "calldata", "GT", "0.0.0"), "rb").read()
+    assert len(raw) < 0.6 * 1024 * 41 * 2                                   # it really is compressed
+    for typesize in (1, 4, 8):                                               # stream splitting / shuffle paths
+        data = np.repeat(rng.integers(0, 50, 5000), 3).astype({1: np.int8, 4: np.int32, 8: np.int64}[typesize]).tobytes()
+        assert G.blosc_decompress(G.blosc_compress(data, typesize)) == data
+    assert G.blosc_decompress(G.blosc_compress(b"", 1)) == b""
+    with pytest.raises(ValueError, match="malformed"):
+        G.blosc_decompress(raw[:len(raw) // 2])
+    zstd = bytearray(raw)
+    zstd[2] = (4 << 5) | (raw[2] & 0x1F)
+    with pytest.raises(ValueError, match="unsupported codec"):
+        G.blosc_decompress(bytes(zstd))
+    bitshuf = bytearray(raw)
+    bitshuf[2] |= 0x04
+    with pytest.raises(ValueError, match="bit-shuffle"):
+        G.blosc_decompress(bytes(bitshuf))
