@@ -196,3 +196,47 @@ def test_load_weights_predicts_without_training_and_edited_callbacks_change_the_
     n_c = len(pd.read_csv(c + "_history.txt", sep="\t"))
     h = pd.read_csv(c + "_history.txt", sep="\t")
     assert n_c < n_a and n_c - 1 - int(h["val_loss"].idxmin()) == 2
+
+
+def _metrics(txt):
+    g = lambda key: float(txt.split(key)[1].split("\n")[0])
+    return g("R2(x)="), g("R2(y)="), g("mean validation error "), g("median validation error ")
+
+
+def test_full_default_run_lands_in_the_readme_band(tmp_path, capsys):
+    """BASELINE.json configs[1]: the reference's example data with every default (patience 100, max_epochs 5000),
+    --seed 12345.  README.md:147-155 prints R2 0.948 / 0.960 and mean error 3.76 for an unseeded reference run; the
+    fp32 oracle's fits on the same split give R2 0.96-0.975 and 2.97-3.36 (tests/golden/oracle_fixture_fits.json)."""
+    _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", str(tmp_path / "d"), "--seed", "12345",
+          "--keras_verbose", "0", "--plot_history", ""])
+    r2x, r2y, mean_err, med_err = _metrics(capsys.readouterr().out)
+    assert r2x >= 0.93 and r2y >= 0.93 and mean_err <= 4.5, (r2x, r2y, mean_err)
+    h = pd.read_csv(str(tmp_path / "d") + "_history.txt", sep="\t")
+    assert 120 <= len(h) <= 600 and h["learning_rate"].iloc[-1] < 1e-3         # early stopping and the LR plateau acted
+
+
+def test_statistical_parity_with_the_oracle_fit_distribution(tmp_path, capsys):
+    """whole fits cannot be compared bit for bit (the reference never seeds TensorFlow), their
+    DISTRIBUTION over seeds can.  Six fp32-oracle fits of the default run are committed
+    (tests/golden/oracle_fixture_fits.json, make_statistical.py); five HIP fits with different --net_seed values must
+    look like draws from the same population: mean validation error within 2.5 pooled standard errors of the oracle
+    mean, every run inside the oracle range widened by 3 sigma, R2 and epoch counts in the oracle's neighbourhood."""
+    ora = json.load(open(os.path.join(GOLD, "oracle_fixture_fits.json")))["fits"]
+    o_err = np.array([f["mean_err"] for f in ora])
+    o_r2 = np.array([[f["r2_x"], f["r2_y"]] for f in ora])
+    o_ep = np.array([f["epochs"] for f in ora])
+    runs = []
+    for s in (11, 22, 33, 44, 55):
+        out = str(tmp_path / f"s{s}")
+        _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", out, "--seed", "12345", "--net_seed", str(s),
+              "--keras_verbose", "0", "--plot_history", ""])
+        r2x, r2y, mean_err, _ = _metrics(capsys.readouterr().out)
+        runs.append((mean_err, r2x, r2y, len(pd.read_csv(out + "_history.txt", sep="\t"))))
+    runs = np.array(runs)
+    sig = max(o_err.std(ddof=1), 0.05)
+    se = sig * np.sqrt(1 / len(o_err) + 1 / len(runs))
+    assert abs(runs[:, 0].mean() - o_err.mean()) < 2.5 * se + 0.05, (runs[:, 0], o_err)
+    assert runs[:, 0].min() > o_err.min() - 3 * sig and runs[:, 0].max() < o_err.max() + 3 * sig, (runs[:, 0], o_err)
+    assert runs[:, 1:3].min() > o_r2.min() - 0.03, (runs[:, 1:3], o_r2)
+    assert 0.5 * o_ep.min() <= np.median(runs[:, 3]) <= 2 * o_ep.max(), (runs[:, 3], o_ep)
+    assert len(set(np.round(runs[:, 0], 6))) == 5                       # the net seed really changes the fit
