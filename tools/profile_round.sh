@@ -1,0 +1,33 @@
+#!/bin/bash
+# Regenerates the round's profile evidence on the GPU box (repo root):  bash tools/profile_round.sh r02
+#   gpurun_out/<tag>_bench_default.json          python3 bench.py --steps 20 --warmup 5          (the driver's command)
+#   gpurun_out/<tag>_bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/<tag>_bench_profiled.json         the bench line printed under the profiler
+#   gpurun_out/<tag>_bench_replicates2.json      python3 bench.py --replicates-per-gpu 2
+#   gpurun_out/<tag>_bench_2ranks_selflaunch.json  python3 bench.py --gpus 2 --device-index 0 --dist-backend gloo (no launcher)
+#   gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+#   gpurun_out/<tag>_gemm_pmc.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters and kernel times
+# Copy what should be judged into profiles/ (tracked).
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+python3 bench.py --steps 50 --warmup 5 --replicates-per-gpu 2 --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_replicates2.json 2>> $O/${TAG}_bench_default.err
+python3 bench.py --gpus 2 --device-index 0 --dist-backend gloo --steps 20 --warmup 5 > $O/${TAG}_bench_2ranks_selflaunch.json 2>> $O/${TAG}_bench_default.err
+cd /tmp
+rm -rf $O/prof_kt
+rocprofv3 --kernel-trace --stats -d $O/prof_kt -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2> $O/prof_kt.err
+cp $O/prof_kt/k_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
+bash $R/tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1
+cp $O/pmc_traffic.json $O/${TAG}_pmc_traffic.json
+bash $R/tools/gemm_pmc.sh > $O/gemm_pmc.log 2>&1
+cp $O/gemm_pmc.json $O/${TAG}_gemm_pmc.json
+rm -rf $O/gemm_kt
+rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
+cp $O/gemm_kt/k_kernel_stats.csv $O/${TAG}_gemm_kernel_stats.csv
+tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
+head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
+tail -6 $O/pmc_traffic.log; tail -4 $O/gemm_pmc.log | cut -c1-400
