@@ -118,12 +118,15 @@ typedef struct loc_net {
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
                                 32-row fp32-MFMA kernel for every block of rows                          */
     void* l1_image;          /* optional: loc_l1_image_bytes(d, pieces) bytes of scratch.  When set, loc_predict over
-                                at least LOC_GEMM_MIN_ROWS rows converts W1 once per call (loc_l1_image_build) and
+                                at least LOC_GEMM_MIN_ROWS(pieces) rows converts W1 once per call (loc_l1_image_build) and
                                 runs every row chunk through loc_l1_forward_gemm; NULL keeps loc_l1_forward_rows */
     int64_t l1_image_bytes;
     loc_tuning tune;
 } loc_net;
-#define LOC_GEMM_MIN_ROWS 768 /* below this the in-loop-conversion kernel is faster than image + GEMM */
+/* Rows from which image + GEMM beats the in-loop-conversion kernel INCLUDING the once-per-call conversion, measured at
+ * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 50 / 30 us plus
+ * 0.176 / 0.065 us per row). */
+#define LOC_GEMM_MIN_ROWS(pieces) ((pieces) >= 3 ? 2048 : (pieces) == 2 ? 1024 : 640)
 
 #define LOC_MAX_FWD_GRID 512
 

@@ -220,7 +220,7 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     if (n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) {
         // large-M layer 1 on the bf16 matrix pipe, then ONE row-parallel stack launch per chunk.  Many rows: the
         // weights are converted once into the caller's image buffer and every chunk runs the pure-MFMA GEMM
-        const bool gemm = n >= LOC_GEMM_MIN_ROWS && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
+        const bool gemm = n >= LOC_GEMM_MIN_ROWS(pieces) && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
                           net->l1_image_bytes >= loc_l1_image_bytes(d, pieces);
         if (gemm) TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {

@@ -19,7 +19,7 @@ LOC_ROWS = 32
 LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
-LOC_GEMM_MIN_ROWS = 768  # include/locator_hip.h
+LOC_GEMM_MIN_ROWS = {3: 2048, 2: 1024, 1: 640}  # include/locator_hip.h, by bf16 pieces
 
 
 def _ptr(t):
@@ -243,7 +243,7 @@ class LocatorNet:
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
-        if (n >= LOC_GEMM_MIN_ROWS and self.l1_image is None and self.predict_pieces > 0
+        if (self.predict_pieces > 0 and n >= LOC_GEMM_MIN_ROWS.get(self.predict_pieces, 1 << 30) and self.l1_image is None
                 and self.lib.loc_l1_gemm_supported(self.d.Hp, self.predict_pieces)):
             # many rows: W1 is converted once per call into this buffer (include/locator_hip.h, loc_net.l1_image)
             self.l1_image = torch.empty(self.lib.loc_l1_image_bytes(C.byref(self.d), self.predict_pieces),

@@ -97,20 +97,24 @@ def test_config2_three_consecutive_steps(config2):
         _step_check(net, x, y, pr, m, v, idx, t, mask_np, w_tol=2e-5)
 
 
-def test_config2_predict_all_rows(config2):
-    """loc_predict over all 1000 rows (large-M bf16x3 layer 1, one stack launch per chunk) vs oracle.predict,
-    plus the per-row validation distances."""
+@pytest.mark.parametrize("pieces,reps", [(3, 1), (3, 3), (1, 1)])
+def test_config2_predict_all_rows(config2, pieces, reps):
+    """loc_predict over all 1000 rows, and over 3000 (every row three times: past LOC_GEMM_MIN_ROWS(3) = 2048, so the
+    first layer runs as image + GEMM, converted once for three 1024-row chunks), vs oracle.predict, plus the per-row
+    validation distances.  One bf16 piece (1000 rows >= 640: image + GEMM too): 2e-2."""
     x, y, p, train, test, pred = config2
-    net = build_net(x, y, p, drop_p=DROP)
-    n = x.shape[0]
-    rows = torch.from_numpy(np.random.default_rng(3).permutation(n).astype(np.int32)).cuda()
+    net = build_net(x, y, p, drop_p=DROP, predict_pieces=pieces)
+    n = x.shape[0] * reps
+    tol = 2e-5 if pieces == 3 else 2e-2
+    rows = torch.from_numpy((np.random.default_rng(3).permutation(n) % x.shape[0]).astype(np.int32)).cuda()
     yhat, dist = torch.zeros((n, 2), device="cuda"), torch.zeros(n, device="cuda")
     net.predict_rows(rows, n, yhat, dist)
     torch.cuda.synchronize()
+    assert (net.l1_image is not None) == (n >= {3: 2048, 1: 640}[pieces])
     r = rows.cpu().numpy()
     ref = O.predict(p, x[r], batch=250)
-    assert maxerr(yhat.cpu().numpy(), ref) < 2e-5, maxerr(yhat.cpu().numpy(), ref)
-    assert maxerr(dist.cpu().numpy(), O.euclid(ref, y[r])) < 2e-5
+    assert maxerr(yhat.cpu().numpy(), ref) < tol, maxerr(yhat.cpu().numpy(), ref)
+    assert maxerr(dist.cpu().numpy(), O.euclid(ref, y[r])) < tol
 
 
 def test_config2_two_epoch_graph_fit_matches_oracle_fit(config2):

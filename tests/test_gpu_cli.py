@@ -131,7 +131,7 @@ def test_batch_size_64_and_rejected_batch_sizes(tmp_path, capsys):
 
 def test_jacknife_is_one_batched_predict_and_matches_the_oracle_on_the_same_perturbed_matrices(tmp_path, monkeypatch):
     """--jacknife: the nboots perturbed copies of the prediction genotypes go through ONE many-row predict (here
-    40 x 50 = 2000 rows: the image + GEMM first layer).  The draws are recorded as the CLI makes them, the perturbed
+    45 x 50 = 2250 rows: the image + GEMM first layer).  The draws are recorded as the CLI makes them, the perturbed
     matrices rebuilt on the host, and every {out}_boot{b}_predlocs.txt compared with oracle.predict on the weights
     the run kept (2e-5 on z-scored outputs, scaled to map units)."""
     from oracle import locator_oracle as O
@@ -155,7 +155,7 @@ def test_jacknife_is_one_batched_predict_and_matches_the_oracle_on_the_same_pert
     monkeypatch.setattr(L, "jacknife_draws", spy_draws)
     monkeypatch.setattr(L.Model, "predict", spy_predict)
     out = str(tmp_path / "j")
-    nboots = 40
+    nboots = 45
     _run(["--matrix", mat, "--sample_data", SAMPLES, "--out", out, "--seed", "7", "--jacknife", "--nboots", str(nboots),
           "--max_epochs", "3", "--patience", "3", "--keras_verbose", "0", "--keep_weights", "--min_mac", "1",
           "--plot_history", ""])
