@@ -114,11 +114,14 @@ def _time_graphed(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def l1_gemm_roofline(net, n_rows, iters=20):
+def l1_gemm_roofline(net, n_matrix, iters=20):
     """The only large-M contraction on the path (model.predict / --jacknife, locator.py:414, :441, :683-747):
-    a1 = ELU(BN(x) W1 + b1) for n_rows rows at once.  flops = 2*M*K*H counted ONCE, however many bf16 pieces carry
-    each fp32 weight (3 = exact products).  `gemm`: weights converted once per sweep (us_prep, not in us) and the
-    pure-MFMA GEMM + its reduction (us); `in_loop`: loc_l1_forward_rows, which converts inside the K loop."""
+    a1 = ELU(BN(x) W1 + b1) for M rows at once.  flops = 2*M*K*H counted ONCE, however many bf16 pieces carry each fp32
+    weight (3 = exact products).  Two shapes: M = every row of the matrix (model.predict over all samples), and
+    M = 4096 rows drawn from it (the shape of the batched --jacknife: nboots x n_pred perturbed rows in one predict;
+    more rows per launch = fewer SNP groups = less partial-sum traffic per flop).  Per shape: image + GEMM (weights
+    converted once per sweep: us_prep, not in us; us = GEMM + its reduction) and `in_loop_conversion`
+    (loc_l1_forward_rows, which converts inside the K loop)."""
     import ctypes as C
 
     import torch
@@ -131,43 +134,51 @@ def l1_gemm_roofline(net, n_rows, iters=20):
     _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
                                             P + 4 * lay.mov_var, bn4.data_ptr(), st()))
     partial = torch.empty(256 * 128 * d.Hp, device=dev)
-    rows = torch.arange(n_rows, dtype=torch.int32, device=dev)
-    a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
-    flops = 2.0 * n_rows * d.K * d.H
-    out = {"rows": n_rows, "flops": flops, "peak_tflops": BF16_PEAK_TFLOPS,
-           "kernel": "l1_gemm_kernel + l1_gemm_reduce_kernel (weights converted once per sweep by l1_image_kernel)"}
 
-    def rec(us, pieces, byts):
-        tf = flops / us * 1e-6
-        return {"us": round(us, 1), "tflops": round(tf, 1), "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
-                "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1),
-                "exact_fp32_products": pieces == 3}
+    def shape(n_rows):
+        rows = (torch.arange(n_rows, dtype=torch.int32, device=dev) % n_matrix).contiguous()
+        a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
+        flops = 2.0 * n_rows * d.K * d.H
+        out = {"rows": n_rows, "flops": flops}
 
-    for pieces in (3, 1):
-        key = "bf16x%d" % pieces
-        if lib.loc_l1_gemm_supported(d.Hp, pieces):
-            image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
-            prep = lambda: _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
-                                                             image.data_ptr(), st()))
-            run = lambda: _lib.check(lib.loc_l1_forward_gemm(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
-                                                             C.byref(d), image.data_ptr(), pieces, P + 4 * lay.b1,
-                                                             partial.data_ptr(), partial.numel(), a1.data_ptr(), 0, st()))
-            prep()
-            us_prep = _time_graphed(prep, 10)
-            us = _time_graphed(run, iters)
-            r = rec(us, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
-            r["us_prep"] = round(us_prep, 1)
-            r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
-            out[key] = r
-            del image
-        if lib.loc_l1_rows_supported(d.Hp, pieces):
-            run = lambda: _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n_rows,
-                                                             C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, P + 4 * lay.b1,
-                                                             partial.data_ptr(), partial.numel(), a1.data_ptr(), pieces,
-                                                             0, None, st()))
-            out.setdefault("in_loop_conversion", {})[key] = rec(_time_graphed(run, iters), pieces,
-                                                                n_rows * d.K + 4.0 * d.K * d.H)
-    return out
+        def rec(us, pieces, byts):
+            tf = flops / us * 1e-6
+            return {"us": round(us, 1), "tflops": round(tf, 1), "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
+                    "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1),
+                    "exact_fp32_products": pieces == 3}
+
+        for pieces in (3, 1):
+            key = "bf16x%d" % pieces
+            if lib.loc_l1_gemm_supported(d.Hp, pieces):
+                image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
+                prep = lambda: _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
+                                                                 image.data_ptr(), st()))
+                run = lambda: _lib.check(lib.loc_l1_forward_gemm(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(),
+                                                                 n_rows, C.byref(d), image.data_ptr(), pieces,
+                                                                 P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
+                                                                 a1.data_ptr(), 0, st()))
+                prep()
+                us_prep = _time_graphed(prep, 10)
+                us = _time_graphed(run, iters)
+                r = rec(us, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
+                r["us_prep"] = round(us_prep, 1)
+                r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
+                out[key] = r
+                del image
+            if lib.loc_l1_rows_supported(d.Hp, pieces):
+                run = lambda: _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(),
+                                                                 n_rows, C.byref(d), bn4.data_ptr(), P + 4 * lay.w1,
+                                                                 P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
+                                                                 a1.data_ptr(), pieces, 0, None, st()))
+                out.setdefault("in_loop_conversion", {})[key] = rec(_time_graphed(run, iters), pieces,
+                                                                    n_rows * d.K + 4.0 * d.K * d.H)
+        return out
+
+    res = shape(n_matrix)
+    res["peak_tflops"] = BF16_PEAK_TFLOPS
+    res["kernel"] = "l1_gemm_kernel + l1_gemm_reduce_kernel (weights converted once per sweep by l1_image_kernel)"
+    res["jacknife_shape_4096_rows"] = shape(4096)
+    return res
 
 
 def cpu_baseline(x, y_norm, train, test, K, H, seconds):

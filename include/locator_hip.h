@@ -47,7 +47,8 @@ extern "C" {
 #define LOC_MAX_BATCH 128 /* --batch_size limit: four 32-row blocks per step                        */
 #define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
-#define LOC_PREDICT_CHUNK 1024 /* rows per large-M launch inside loc_predict                      */
+#define LOC_PREDICT_CHUNK 4096 /* rows per large-M launch inside loc_predict (more rows per launch = fewer SNP
+                                  groups = less partial-sum traffic: 0.135 -> 0.154 of bf16 peak from 1024 to 4096) */
 #define LOC_ROWS_BLOCKS 256    /* 128-row tiles the large-M scratch is sized for (one workgroup per CU)   */
 
 typedef struct loc_dims {
