@@ -88,34 +88,34 @@ def main():
             def prep():
                 _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
                                                   image.data_ptr(), None))
-
-            def run():
-                _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
-                                                   image.data_ptr(), pieces, P + 4 * lay.b1, partial.data_ptr(),
-                                                   256 * 128 * d.Hp, a1.data_ptr(), 0, None))
-            t = {}
-            for name, fn in (("prep", prep), ("gemm", run)):
-                for _ in range(5):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(a.iters):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
-            flops = 2.0 * n * a.snps * a.width
-            byts = n * a.snps + 2.0 * pieces * a.snps * a.width
-            rec = {"kernel": "image+gemm", "rows": n, "snps": a.snps, "width": a.width, "pieces": pieces,
-                   "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
-                   "tflops": round(flops / t["gemm"] * 1e-6, 1),
-                   "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
-                   "frac_bf16_peak_incl_prep": round(flops / (t["gemm"] + t["prep"]) * 1e-6 / BF16_PEAK_TFLOPS, 4),
-                   "mfma_issue_frac": round(pieces * flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
-                   "gbs": round(byts / t["gemm"] * 1e-3, 1)}
-            print(json.dumps(rec), flush=True)
-            out.append(rec)
+            for blocks in [int(b) for b in a.blocks.split(",")]:
+                def run():
+                    _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
+                                                       image.data_ptr(), pieces, P + 4 * lay.b1, partial.data_ptr(),
+                                                       partial.numel(), a1.data_ptr(), blocks, None))
+                t = {}
+                for name, fn in (("prep", prep), ("gemm", run)):
+                    for _ in range(5):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(a.iters):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+                flops = 2.0 * n * a.snps * a.width
+                byts = n * a.snps + 2.0 * pieces * a.snps * a.width
+                rec = {"kernel": "image+gemm", "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
+                       "pieces": pieces, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
+                       "tflops": round(flops / t["gemm"] * 1e-6, 1),
+                       "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "frac_bf16_peak_incl_prep": round(flops / (t["gemm"] + t["prep"]) * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "mfma_issue_frac": round(pieces * flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "gbs": round(byts / t["gemm"] * 1e-3, 1)}
+                print(json.dumps(rec), flush=True)
+                out.append(rec)
     return out
 
 
