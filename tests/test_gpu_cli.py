@@ -240,3 +240,54 @@ def test_statistical_parity_with_the_oracle_fit_distribution(tmp_path, capsys):
     assert runs[:, 1:3].min() > o_r2.min() - 0.03, (runs[:, 1:3], o_r2)
     assert 0.5 * o_ep.min() <= np.median(runs[:, 3]) <= 2 * o_ep.max(), (runs[:, 3], o_ep)
     assert len(set(np.round(runs[:, 0], 6))) == 5                       # the net seed really changes the fit
+
+
+def test_config3_windows_end_to_end_at_ag1000g_window_size(tmp_path, capsys):
+    """BASELINE.json configs[3], two of its windows at full width: a synthetic `allel.vcf_to_zarr`-shaped store of 765
+    samples x 2 windows x 150,000 variants (2 Mb each), `--windows --window_size 2000000`, callback-driven fits (two
+    worker processes on the GPU).  Every window writes its predlocs / history under the reference's names, and the
+    76 samples without coordinates are placed near where the generator put them (coordinates span 0..50)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_synth_zarr", os.path.join(os.path.dirname(GOLD), "..", "tools",
+                                                                                  "make_synth_zarr.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    stem = str(tmp_path / "c3")
+    xy, na = mk.make_store(stem, n=765, windows=2, window_size=2_000_000, per_window=150_000, seed=5)
+    out = str(tmp_path / "win")
+    _run(["--zarr", stem + ".zarr", "--sample_data", stem + "_samples.txt", "--out", out, "--windows",
+          "--window_size", "2000000", "--seed", "12345", "--keras_verbose", "0", "--plot_history", ""])
+    size = 2_000_000
+    ids = np.array([f"AB{i:04d}" for i in range(765)])
+    for w in (0, 1):
+        stem_w = f"{out}_{w * size}-{(w + 1) * size - 1}"
+        pl = pd.read_csv(f"{stem_w}_0-{size - 1}_predlocs.txt")            # the reference's doubled window name (SURVEY Q3)
+        h = pd.read_csv(f"{stem_w}_history.txt", sep="\t")
+        assert list(pl["sampleID"]) == list(ids[na]) and 20 <= len(h) <= 2000
+        err = np.sqrt((pl["x"].to_numpy() - xy[na, 0]) ** 2 + (pl["y"].to_numpy() - xy[na, 1]) ** 2)
+        assert err.mean() < 6.0, err.mean()                                 # full-size run: 2.7-3.8 per window
+
+
+def test_config4_bootstrap_end_to_end_at_500k_snps(tmp_path):
+    """BASELINE.json configs[4] at its matrix width, with few replicates and a bounded epoch count: 1000 samples x
+    520,000 variants (> 500,000 SNPs survive the filters), `--bootstrap --nboots 3` (FULL + 3 resampled fits, two
+    worker processes on the GPU, genotype rows handed over through shared memory, column resampling on the device).
+    Every replicate writes its predlocs; resampled replicates differ from the full fit; the 100 samples without
+    coordinates land near the truth already after 30 epochs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_synth_zarr", os.path.join(os.path.dirname(GOLD), "..", "tools",
+                                                                                  "make_synth_zarr.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    stem = str(tmp_path / "c4")
+    xy, na = mk.make_store(stem, n=1000, windows=1, window_size=50_000_000, per_window=520_000, seed=9)
+    out = str(tmp_path / "boot")
+    _run(["--zarr", stem + ".zarr", "--sample_data", stem + "_samples.txt", "--out", out, "--bootstrap", "--nboots", "3",
+          "--seed", "12345", "--max_epochs", "30", "--patience", "30", "--keras_verbose", "0", "--plot_history", ""])
+    preds = {b: pd.read_csv(f"{out}_boot{b}_predlocs.txt") for b in ("FULL", "0", "1", "2")}
+    for b, pl in preds.items():
+        assert len(pl) == 100
+        err = np.sqrt((pl["x"].to_numpy() - xy[na, 0]) ** 2 + (pl["y"].to_numpy() - xy[na, 1]) ** 2)
+        assert err.mean() < 8.0, (b, err.mean())
+    assert not np.allclose(preds["FULL"]["x"], preds["0"]["x"]) and not np.allclose(preds["0"]["x"], preds["1"]["x"])
+    assert len(pd.read_csv(out + "_history.txt", sep="\t")) == 30
