@@ -15,34 +15,47 @@
 //                        8+8+8-bit truncation split (fp32-exact products), 1 piece = round-to-nearest bf16.  Also the
 //                        per-unit shift term c[h] = sum_k t_k W1[k][h] (per-block partial sums, fixed-order reduction).
 //                        Streams at the HBM rate (26 us for 1 piece, 46 us for 3 at K = 100,000).
-//   l1_gemm_kernel       workgroup = 8 waves on a 128-row x 256-unit tile, split over SNP blocks (strided, like
-//                        l1_rows).  A wave owns 32 units and ALL 128 rows (4 row tiles x 1 unit tile), so its weight
-//                        fragments are private: they go HBM/L2 -> VGPRs in the B-operand layout (plain 16-byte
-//                        loads, two tiles ahead, three static register sets) and never touch the LDS.  Only the
-//                        genotype block is shared: u8 rows -> registers -> bf16 image in the LDS (1 cvt + 1/2 perm
-//                        per genotype, once per workgroup and SNP block - the only vector work in the loop),
-//                        conflict-free for both the 16-byte writes and the MFMA A-operand reads; one barrier per
-//                        SNP block (every P weight tiles).  MFMA 32x32x16 bf16, fp32 accumulation.
+//   l1_gemm_kernel       workgroup = 8 waves on a 128-row x 256-unit tile, split over SNP groups (a group owns every
+//                        G-th PAIR of adjacent 64-SNP blocks).  A wave owns 32 units and ALL 128 rows (4 row tiles x 1
+//                        unit tile), so its weight fragments are private: HBM/L2 -> VGPRs in the B-operand layout
+//                        (16-byte loads, three tiles ahead, three static register sets), never through the LDS.  Only
+//                        the genotype block is shared: u8 rows -> registers -> bf16 image in a 4-slot LDS ring (1 cvt
+//                        + 1/2 perm per genotype, once per workgroup and block), read as MFMA A operands by 16-byte
+//                        loads; reads and writes are bank-conflict free.  A genotype request covers the pair's whole
+//                        128-byte line of a row (8 lanes a row).  The two halves of the workgroup (waves 0-3 / 4-7:
+//                        the two waves of each SIMD) run half a block apart between two barriers per block: one
+//                        issues the block's P x 16 MFMAs from registers while its SIMD partner reads fragments, widens
+//                        and requests.  Global requests are asm with hand-counted vmcnt.  MFMA 32x32x16 bf16, fp32
+//                        accumulation.
 //   l1_gemm_reduce_kernel  fixed-order sum of the SNP-group partials + shift term + b1, ELU.
 //
-// Blocks that share a SNP group (same weight tiles, different row tiles) sit on one XCD (block b runs on XCD b % 8),
-// and so do the two groups that read the two 64-byte halves of the same 128-byte genotype lines: a weight tile or a
-// genotype line leaves HBM once.  Placement is a speed hint only.
+// Blocks that share a SNP group (same weight tiles, different row tiles) sit on one XCD (block b runs on XCD b % 8): a
+// weight tile leaves HBM once.  Placement is a speed hint only.
 //
-// What was built and measured on the way (1000 rows x 100,000 SNPs x 256 units, rocprofv3 kernel time, 1 piece /
-// 3 pieces; in-kernel s_memtime stamps and PMC in profiles/r02_gemm_*; the four schedules are in the git history):
+// What was built and measured on the way (1000 rows x 100,000 SNPs x 256 units, kernel time 1 piece / 3 pieces;
+// in-kernel s_memtime stamps, timing ablations and PMC in profiles/r02_gemm_*; the schedules are in the git history):
 //   (1) LDS-DMA lockstep: weight tiles and raw genotypes by global_load_lds into a 3-slot ring, counted vmcnt,
 //       raw s_barrier per tile, 160 KB LDS: 70 / 147 us.  Ablations add up instead of overlapping (genotype widening
 //       +11 us, weight requests +13, fragment reads +9.5 on a 36 us matrix-only run): one global_load_lds costs the
 //       issuing wave ~150 cycles, and all eight waves do the same thing at the same time.
-//   (2) two groups of four waves half a step apart (one in its matrix segment while its partner stages): 73 / 163 us:
-//       a matrix segment stretches from 750 to 1,100-1,700 cycles whenever the partner moves data through the LDS.
+//   (2) the same with two groups of four waves half a step apart: 73 / 163 us (a matrix segment stretches from 750 to
+//       1,100-1,700 cycles whenever the partner moves data through the LDS by DMA).
 //   (3) register-staged tiles (global -> VGPR -> ds_write_b128), one barrier per tile: 63 / 151 us.
-//   (4) this kernel: 60 / 145 us, matrix pipe 48 % / 57 % busy, VALU 11 % / 8 %.  Holding the genotype fragments in
-//       registers across the three pieces, or cutting the weight / fragment traffic 4x (timing ablations), moves it
-//       by < 10 %: what is left is wave-level stall time the compiler's schedule leaves between dependent groups
-//       (42 % of wave cycles parked in s_waitcnt / s_barrier).
+//   (4) weight fragments straight to VGPRs, only genotypes through the LDS, all 8 waves in lockstep, one barrier per
+//       block: 60 / 145 us, matrix pipe 48 % / 57 % busy.  Stamps: per block ~1,000 cycles of MFMA issue for both
+//       waves of a SIMD, then ~700-1,000 cycles in which neither issues one (widen + requests + barrier skew).
+//   (5) this kernel.  Steps, each measured at 4096 rows, 1 piece: (4) 221 us -> half-a-block phase shift between the
+//       two waves of each SIMD, A fragments held in registers across the phase: 209 -> weight requests interleaved
+//       one per 4 MFMAs (a request stalls its wave ~100 cycles; the 4 queued MFMAs cover it): 205 -> 128-byte
+//       genotype lines (8 rows per request instead of 16 half lines; ablation: the genotype REQUEST, not the widening
+//       or the LDS traffic, was the most expensive item, 55 us of 209): -> hand-counted vmcnt (the compiler's counts
+//       were 1-4 where 9-14 are right after its loop-header merge): 193 us.  1000 rows: 57 / 139 us.
+//       What is left (ablations at 4096 rows, 1 piece): MFMAs + barriers alone 127 us (0.66 of the bf16 peak: the
+//       clock under sustained MFMA load), weight requests +25, genotype stream +30 when it comes from HBM / MALL
+//       (+5 when the same lines are L2-hot; vmcnt returns in order, so a slow genotype line holds back the weight
+//       fragments queued behind it), deeper genotype prefetch (6 blocks) and s_setprio either way: no gain.
 #include "common.h"
+#include <type_traits>
 
 #define GM_BM 128
 #define GM_BK 64
@@ -50,7 +63,7 @@
 #define GM_HP 256
 #define GM_BTILE (GM_HP * GM_BK * 2) /* 32768: one (SNP block, piece) weight tile, bf16 */
 #define GM_AIMG (GM_BM * GM_BK * 2)  /* 16384: bf16 genotype image of one SNP block    */
-#define GM_LDS 131072                /* 2 genotype images in the loop; the epilogue stages 8 x 16 KB of partials */
+#define GM_LDS 131072                /* 4 genotype images in the loop; the epilogue stages 8 x 16 KB of partials */
 
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t rne16g(uint32_t u) { return u + 0x7FFFu + ((u >> 16) & 1u); }
@@ -137,24 +150,49 @@ __global__ __launch_bounds__(1024) void l1_image_cvec_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr32(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// four A fragments (row tiles 0..3 of one k-step) by four 16-byte LDS reads; volatile so that they stay in the load
+// phase, ahead of the barrier that hands the matrix pipe to this wave
+__device__ __forceinline__ void rd4(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\t"
+                 "ds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(addr) : "memory");
+}
+// Global loads as asm with hand-counted s_waitcnt vmcnt: the compiler's own bookkeeping merges the prologue's and the
+// loop's in-flight state at the loop header and then waits for almost everything in the first blocks of every
+// unrolled body (seen as vmcnt(2) where 9 loads may stay in flight).  The counts are in the loop below.
+template <typename T>
+__device__ __forceinline__ void gload16(T& r, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// LDS traffic of this wave done, then the workgroup barrier (no vmcnt wait: weight / genotype requests stay in flight)
+// and nothing (MFMAs included) scheduled across it
+__device__ __forceinline__ void phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int P>
 __global__ __launch_bounds__(GM_NT) void l1_gemm_kernel(const uint8_t* __restrict__ X, int64_t pitch,
                                                          const int32_t* __restrict__ rows, int n, int Kp,
                                                          const unsigned char* __restrict__ tiles,
-                                                         float* __restrict__ partial, int G, int n_mt, int nkt64) {
+                                                         float* __restrict__ partial, int G, int n_mt, int npairs) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char gm_smem[];
-    unsigned char* const As = gm_smem;                         // 2 x 16 KB (the epilogue reuses 8 x 16 KB)
+    unsigned char* const As = gm_smem;                         // 4 x 16 KB in the loop (the epilogue reuses 8 x 16 KB)
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int jl = lane & 31, hi = lane >> 5;
     int g, mt;
-    if ((G & 15) == 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        mt = idx % n_mt;
-        const int r = idx / n_mt;
-        g = 2 * xcd + (r & 1) + 16 * (r >> 1);
-    } else if ((G & 7) == 0) {
+    if ((G & 7) == 0) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         mt = idx % n_mt;
         g = xcd + 8 * (idx / n_mt);
@@ -163,20 +201,30 @@ __global__ __launch_bounds__(GM_NT) void l1_gemm_kernel(const uint8_t* __restric
         mt = blockIdx.x / G;
     }
     const int Mp = n_mt * GM_BM;
-    const int cnt = (nkt64 - g + G - 1) / G;
-    const int nB = cnt * P;
+    // this group's SNP blocks: pairs c = 0..cntp-1 of adjacent blocks, block a = 2c + e  <->  kt64 = 2 (g + c G) + e
+    const int cntp = (npairs - g + G - 1) / G;
+    const int cnt = 2 * cntp, nB = cnt * P;
 
-    const int xm = t >> 2, xj = t & 3;
-    int xrow_i = mt * GM_BM + xm;
-    if (xrow_i > n - 1) xrow_i = n - 1;
-    const uint8_t* const xsrc = X + (int64_t)rows[xrow_i] * pitch;
-    auto load_x = [&](u32x4& R, int ai) {
-        const int a = ai < cnt ? ai : cnt - 1;
-        int koff = (g + a * G) * GM_BK + 16 * xj;
-        if (koff > Kp - 16) koff = Kp - 16;
-        R = *reinterpret_cast<const u32x4*>(xsrc + koff);
+    // genotypes: a thread moves 16 bytes (piece q of a pair's 128-byte line) of rows xr and xr + 64
+    const int xr = t >> 3, q = t & 7;
+    const uint8_t* xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int r = mt * GM_BM + xr + 64 * i;
+        if (r > n - 1) r = n - 1;
+        xsrc[i] = X + (int64_t)rows[r] * pitch;
+    }
+    auto load_x = [&](u32x4& R, int c, int i) {
+        const int cc = c < cntp ? c : cntp - 1;
+        int koff = (g + cc * G) * (2 * GM_BK) + 16 * q;
+        if (koff > Kp - 16) koff = Kp - 16;                    // only in the zero-weight padding of the last pair
+        gload16(R, xsrc[i] + koff);
     };
-    auto widen = [&](const u32x4& R, int islot) {
+    // image of block a: chunk c8 (8 SNPs) of row m at  c8*2048 + ((m ^ (c8 & 6) ^ (a & 1)) << 4)  - the 8 lanes of
+    // one 16-byte store group (one row, both blocks of the pair) fall on 8 different 16-byte bank groups, and so do
+    // the 16 lanes of one read group
+    const uint32_t woff = (q >> 2) * GM_AIMG + (2 * (q & 3)) * 2048 + ((xr ^ (2 * (q & 3)) ^ (q >> 2)) << 4);
+    auto widen = [&](const u32x4& R, int c, int i) {
         u32x4 o0, o1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -186,78 +234,119 @@ __global__ __launch_bounds__(GM_NT) void l1_gemm_kernel(const uint8_t* __restric
             if (d < 2) { o0[2 * d] = lo; o0[2 * d + 1] = hh; }
             else { o1[2 * (d - 2)] = lo; o1[2 * (d - 2) + 1] = hh; }
         }
-        unsigned char* ad = As + islot * GM_AIMG + ((xm ^ (2 * xj)) << 4);
-        *reinterpret_cast<u32x4*>(ad + (2 * xj) * 2048) = o0;
-        *reinterpret_cast<u32x4*>(ad + (2 * xj + 1) * 2048) = o1;
+        unsigned char* ad = As + woff + ((2 * c) & 3) * GM_AIMG + i * 1024;
+        *reinterpret_cast<u32x4*>(ad) = o0;
+        *reinterpret_cast<u32x4*>(ad + 2048) = o1;
     };
-    // this wave's weight fragments of tile j: chunk 2 kk + hi, unit w*32 + jl
+    // this wave's weight fragments of tile j (block j / P, piece j % P): chunk 2 kk + hi, unit w*32 + jl
     struct bregs { bf16x8 b[4]; };
     const int b_lane = hi * 4096 + (w * 32 + jl) * 16;
-    auto load_b = [&](bregs& R, int j) {
+    auto load_b_part = [&](bregs& R, int j, int k0, int k1) {
         const int jj = j < nB ? j : nB - 1;
-        const int kt = g + (jj / P) * G, p = jj % P;
+        const int a = jj / P, p = jj - a * P;
+        const int kt = 2 * (g + (a >> 1) * G) + (a & 1);
         const unsigned char* src = tiles + ((int64_t)kt * P + p) * GM_BTILE + b_lane;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) R.b[kk] = *reinterpret_cast<const bf16x8*>(src + kk * 8192);
+        for (int kk = k0; kk < k1; ++kk) gload16(R.b[kk], src + kk * 8192);
     };
 
     f32x16 acc[4];
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) acc[tm] = f32x16{0};
-    auto mma_tile = [&](const unsigned char* Ab, const bregs& R) {
+    uint32_t aoff[2][4];                                        // A-fragment addresses for even / odd blocks
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const unsigned char* ap = Ab + (2 * kk + hi) * 2048 + ((jl ^ (2 * kk)) << 4);
-            bf16x8 a[4];
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(ap + tm * 512);
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], R.b[kk], acc[tm], 0, 0, 0);
-        }
-    };
+        for (int kk = 0; kk < 4; ++kk)
+            aoff[e][kk] = lds_addr32(As) + (2 * kk + hi) * 2048 + ((jl ^ (2 * kk) ^ e) << 4);
 
-    // prologue: genotype blocks 0 (widened at once), 1, 2 and weight tiles 0, 1 requested
-    u32x4 X0, X1;
+    // prologue: pair 0 widened at once, pair 1 and weight tiles 0..2 requested
+    u32x4 XR[2];
     bregs B0, B1, B2;
     {
-        u32x4 xt;
-        load_x(xt, 0);
-        load_x(X1, 1);
-        load_x(X0, 2);
-        load_b(B0, 0);
-        load_b(B1, 1);
-        widen(xt, 0);
+        u32x4 x0, x1;
+        load_x(x0, 0, 0);
+        load_x(x1, 0, 1);
+        load_x(XR[0], 1, 0);
+        load_x(XR[1], 1, 1);
+        load_b_part(B0, 0, 0, 4);
+        load_b_part(B1, 1, 0, 4);
+        load_b_part(B2, 2, 0, 4);
+        wait_vm<0>();
+        widen(x0, 0, 0);
+        widen(x1, 0, 1);
     }
     __syncthreads();
 
-    // U tiles per unrolled body: register set of tile j = j % 3, genotype image slot = (j / P) % 2, all static
-    constexpr int U = (P == 2) ? 12 : 6;
-    for (int base = 0; base < nB; base += U) {
+    // Two groups of four waves (one wave per SIMD each: waves w and w + 4 share a SIMD) run half a block apart.  In
+    // its load phase a wave reads the block's 16 A fragments into registers, widens its share of the NEXT pair of
+    // blocks into the ring and requests the pair after that; in its matrix phase it issues the block's P x 16 MFMAs
+    // from registers only, each group of 4 followed by the request for the weight fragment it just consumed, three
+    // tiles ahead.  The phases of the two groups alternate between the same barriers, so a SIMD's matrix pipe is
+    // fed by one wave while its partner moves data.
+    const int grp = w >> 2;
+    if (grp == 1) phase_barrier();
+    constexpr int NBLK = (P == 3) ? 2 : 6;                      // unrolled blocks: register set and block parity static
+    auto block = [&](int bb, auto alc) {
+        constexpr int al = decltype(alc)::value;
+        const int ai = bb + al;
+        const uint32_t so = (ai & 3) * GM_AIMG;
+        bf16x8 a[4][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = base + u;
-            const int p = u % P, al = u / P;                  // SNP block of tile j = base / P + al, al & 1 = its image slot
-            const int ai = base / P + al;
-            // weight tile j + 2 into the set tile j - 1 used
-            if (u % 3 == 0) load_b(B2, j + 2);
-            else if (u % 3 == 1) load_b(B0, j + 2);
-            else load_b(B1, j + 2);
-            if (p == 0) {
-                // the NEXT SNP block's genotypes: widen into the other image slot (free since the last barrier), then
-                // request the block after the next two into the registers just consumed
-                if ((al & 1) == 0) { widen(X1, 1); load_x(X1, ai + 3); }
-                else { widen(X0, 0); load_x(X0, ai + 3); }
+        for (int kk = 0; kk < 4; ++kk) rd4(a[kk][0], a[kk][1], a[kk][2], a[kk][3], aoff[al & 1][kk] + so);
+        // vmcnt is in order.  A block issues 1 genotype request, then 4 weight requests per tile.  The genotypes
+        // widened now were requested two blocks ago: 4P + 1 + 4P younger requests may stay in flight.
+        wait_vm<8 * P + 1>();
+        widen(XR[al & 1], (ai >> 1) + 1, al & 1);
+        load_x(XR[al & 1], (ai >> 1) + 2, al & 1);
+        phase_barrier();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int u = al * P + p;
+            bregs& Bc = (u % 3 == 0) ? B0 : (u % 3 == 1) ? B1 : B2;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // fragment kk of this tile was requested three tiles ago: 11 weight requests since, plus one genotype
+                // request per block boundary crossed on the way (p folds after unrolling)
+                if (P == 1) wait_vm<14>();
+                else if (P == 2 && p == 0) wait_vm<13>();
+                else wait_vm<12>();
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][tm], Bc.b[kk], acc[tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b_part(Bc, bb * P + u + 3, kk, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (j < nB) {
-                const unsigned char* Ab = As + (al & 1) * GM_AIMG;
-                if (u % 3 == 0) mma_tile(Ab, B0);
-                else if (u % 3 == 1) mma_tile(Ab, B1);
-                else mma_tile(Ab, B2);
-            }
-            if (p == P - 1) __syncthreads();
+        }
+        phase_barrier();
+    };
+    // whole bodies without a branch inside (the compiler's vmcnt bookkeeping stays exact), then the remainder
+    int bb = 0;
+    for (; bb + NBLK <= cnt; bb += NBLK) {
+        block(bb, std::integral_constant<int, 0>{});
+        block(bb, std::integral_constant<int, 1>{});
+        if (NBLK == 6) {
+            block(bb, std::integral_constant<int, 2>{});
+            block(bb, std::integral_constant<int, 3>{});
+            block(bb, std::integral_constant<int, 4>{});
+            block(bb, std::integral_constant<int, 5>{});
         }
     }
+    if (NBLK == 6 && bb < cnt) {                                // cnt is even: 2 or 4 blocks left
+        block(bb, std::integral_constant<int, 0>{});
+        block(bb, std::integral_constant<int, 1>{});
+        if (bb + 2 < cnt) {
+            block(bb, std::integral_constant<int, 2>{});
+            block(bb, std::integral_constant<int, 3>{});
+        }
+    }
+    // requests past the end (clamped, never used) are still landing: drain them while their registers are still
+    // allocated - the empty asm after the wait is what keeps the compiler from re-using one of them before it
+    wait_vm<0>();
+    asm volatile("" ::"v"(B0.b[0]), "v"(B0.b[1]), "v"(B0.b[2]), "v"(B0.b[3]), "v"(B1.b[0]), "v"(B1.b[1]), "v"(B1.b[2]),
+                 "v"(B1.b[3]), "v"(B2.b[0]), "v"(B2.b[1]), "v"(B2.b[2]), "v"(B2.b[3]), "v"(XR[0]), "v"(XR[1]));
+    if (grp == 0) phase_barrier();
 
     // D[i = row][j = unit]: wave tile 128 rows x 32 units through a wave-private LDS image, then 16-byte stores
     float* const ep = reinterpret_cast<float*>(gm_smem) + w * 4096;
@@ -312,7 +401,8 @@ __global__ __launch_bounds__(256) void l1_gemm_reduce_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static int gm_nkt64(const loc_dims* d) { return (d->Kp + GM_BK - 1) / GM_BK; }
+// 64-SNP blocks of the image, rounded up to whole pairs (a zero-weight tile pads an odd count)
+static int gm_nkt64(const loc_dims* d) { return ((d->Kp + GM_BK - 1) / GM_BK + 1) & ~1; }
 
 extern "C" int loc_l1_gemm_supported(int Hp, int pieces) { return Hp == GM_HP && pieces >= 1 && pieces <= 3; }
 
@@ -378,7 +468,7 @@ extern "C" int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int3
     int G = target_blocks / n_mt;
     const int64_t cap = partial_floats / ((int64_t)Mp * GM_HP);
     if (G > cap) G = (int)cap;
-    if (G > nkt) G = nkt;
+    if (G > nkt / 2) G = nkt / 2;
     if (G >= 8) G &= ~7;
     if (G < 1) { loc_set_error("loc_l1_forward_gemm: scratch too small for %d rows", n); return -1; }
     const unsigned char* base = static_cast<const unsigned char*>(image);
@@ -390,7 +480,7 @@ extern "C" int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int3
         int rc = gm_set_lds(l1_gemm_kernel<PP>);                                                               \
         if (rc) return rc;                                                                                     \
         hipLaunchKernelGGL(l1_gemm_kernel<PP>, dim3(n_mt * G), dim3(GM_NT), GM_LDS, st, X, x_pitch, rows, n,   \
-                           d->Kp, tiles, partial, G, n_mt, nkt);                                               \
+                           d->Kp, tiles, partial, G, n_mt, nkt / 2);                                           \
     }
     switch (pieces) {
         case 1: GM_LAUNCH(1) break;
