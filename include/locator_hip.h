@@ -125,9 +125,9 @@ typedef struct loc_net {
     loc_tuning tune;
 } loc_net;
 /* Rows from which image + GEMM beats the in-loop-conversion kernel INCLUDING the once-per-call conversion, measured at
- * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 50 / 30 us plus
- * 0.176 / 0.065 us per row). */
-#define LOC_GEMM_MIN_ROWS(pieces) ((pieces) >= 3 ? 2048 : (pieces) == 2 ? 1024 : 640)
+ * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 51 / 30 us plus
+ * 60 + 0.095 / 20 + 0.036 us per row). */
+#define LOC_GEMM_MIN_ROWS(pieces) ((pieces) >= 3 ? 1152 : (pieces) == 2 ? 768 : 640)
 
 #define LOC_MAX_FWD_GRID 512
 

@@ -29,7 +29,7 @@
 // (429 TFLOP/s, 0.17 of peak); the 32-row fp32-MFMA kernel needs 32 launches x 24 us for the same rows.
 // PMC (rocprofv3): per wave MFMA-busy 41 %, VALU (the fp32 -> bf16 split) 31 %, waits 28 %, LDS bank
 // conflicts 1/3 of LDS cycles before the store-order fix in conv_w.  The conversion, not the matrix pipe, bounds
-// this kernel when the same weights serve many row tiles: from LOC_GEMM_MIN_ROWS(pieces) rows on (2048 with three pieces), loc_predict converts once
+// this kernel when the same weights serve many row tiles: from LOC_GEMM_MIN_ROWS(pieces) rows on (1152 with three pieces), loc_predict converts once
 // per call into an HBM bf16 image and runs l1_gemm.hip instead; this kernel stays the one for few rows (the
 // per-epoch validation sweep), where the conversion is used once.
 #include "common.h"

@@ -19,7 +19,7 @@ LOC_ROWS = 32
 LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
-LOC_GEMM_MIN_ROWS = {3: 2048, 2: 1024, 1: 640}  # include/locator_hip.h, by bf16 pieces
+LOC_GEMM_MIN_ROWS = {3: 1152, 2: 768, 1: 640}  # include/locator_hip.h, by bf16 pieces
 
 
 def _ptr(t):

@@ -99,7 +99,7 @@ def test_config2_three_consecutive_steps(config2):
 
 @pytest.mark.parametrize("pieces,reps", [(3, 1), (3, 3), (1, 1)])
 def test_config2_predict_all_rows(config2, pieces, reps):
-    """loc_predict over all 1000 rows, and over 3000 (every row three times: past LOC_GEMM_MIN_ROWS(3) = 2048, so the
+    """loc_predict over all 1000 rows, and over 3000 (every row three times: past LOC_GEMM_MIN_ROWS(3) = 1152, so the
     first layer runs as image + GEMM, converted once for three 1024-row chunks), vs oracle.predict, plus the per-row
     validation distances.  One bf16 piece (1000 rows >= 640: image + GEMM too): 2e-2."""
     x, y, p, train, test, pred = config2
@@ -110,7 +110,7 @@ def test_config2_predict_all_rows(config2, pieces, reps):
     yhat, dist = torch.zeros((n, 2), device="cuda"), torch.zeros(n, device="cuda")
     net.predict_rows(rows, n, yhat, dist)
     torch.cuda.synchronize()
-    assert (net.l1_image is not None) == (n >= {3: 2048, 1: 640}[pieces])
+    assert (net.l1_image is not None) == (n >= {3: 1152, 1: 640}[pieces])
     r = rows.cpu().numpy()
     ref = O.predict(p, x[r], batch=250)
     assert maxerr(yhat.cpu().numpy(), ref) < tol, maxerr(yhat.cpu().numpy(), ref)
