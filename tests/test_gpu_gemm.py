@@ -103,6 +103,23 @@ def test_gemm_is_deterministic_and_agrees_with_the_in_loop_conversion_kernel():
     assert maxerr(a[:n], d[:n]) < 5e-6
 
 
+@pytest.mark.parametrize("pieces,target_blocks", [(1, 0), (2, 0), (3, 0), (1, 48), (2, 24), (3, 8)])
+def test_gemm_every_loop_shape_matches_the_three_piece_result_structure(pieces, target_blocks):
+    """The unrolled body holds 6 SNP blocks (1 or 2 pieces) or 2 (3 pieces) and a remainder of 2 or 4 blocks follows it;
+    the number of SNP groups decides how many blocks a workgroup walks.  K = 20,000 is 313 blocks (odd: one zero tile
+    pads the last pair); 1000 rows at the default 256 workgroups = 32 groups of 8-10 blocks, and fewer workgroups
+    = longer walks (48 -> 6 groups of 52-54 blocks, 24 -> 3 of 104-106, 8 -> 1 group of all 314).  Every row and unit
+    is compared with the fp64 forward."""
+    K, width, n = 20000, 256, 1000
+    x, y, p, rng = make_problem(n, K, width, 2, seed=11 + pieces)
+    net = build_net(x, y, p)
+    r = rng.permutation(n).astype(np.int32)
+    a1 = run_gemm(net, torch.from_numpy(r).cuda(), n, pieces, target_blocks=target_blocks)
+    ref, z = _a1_reference(p, x[r])
+    err = maxerr(a1[:n, :width], ref)
+    assert err < {3: 3e-5, 2: 4e-4, 1: 4e-2}[pieces], err
+
+
 def test_gemm_rejects_what_it_cannot_do():
     from locator_amd import _lib
     x, y, p, rng = make_problem(40, 256, 128, 2, seed=9)
