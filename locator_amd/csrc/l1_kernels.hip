@@ -268,37 +268,46 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
 }
 
 // a1[b][h] = ELU(sum_g partial[g][b][h] + b1[h]); optional Dropout on this layer's output.
-// Block = 1024 threads = 64 consecutive outputs x 16 groups of partials; fixed summation order.
-__global__ __launch_bounds__(1024) void l1_reduce_kernel(const float* __restrict__ partial, int G, int rows_p,
-                                                         int Hp, const float* __restrict__ b1,
-                                                         float* __restrict__ a1,
-                                                         float* __restrict__ a1_drop,
-                                                         const uint8_t* __restrict__ mask, float keep_scale) {
-    __shared__ float red[16][64];
-    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
-    const int n = rows_p * Hp;
-    float bias = 0.f, keep = 1.f;
-    if (q == 0) {
-        bias = b1[idx % Hp];
-        if (mask) keep = mask[idx] ? keep_scale : 0.f;
-    }
-    float s0 = 0.f, s1 = 0.f;
+// Block = 256 threads = 16 consecutive float4 outputs x 16 groups of partials; a thread has its 16-byte loads of 16
+// groups in flight at once (the partials sit in other XCDs' L2 or in the Infinity Cache: one round trip per 16 groups
+// instead of one per two), the 16 group sums are then added through LDS in a fixed order.
+__global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict__ partial, int G, int rows_p,
+                                                        int Hp, const float* __restrict__ b1,
+                                                        float* __restrict__ a1,
+                                                        float* __restrict__ a1_drop,
+                                                        const uint8_t* __restrict__ mask, float keep_scale) {
+    __shared__ f32x4 red[16][16];
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int64_t idx = ((int64_t)blockIdx.x * 16 + o) * 4;
+    const int64_t n = (int64_t)rows_p * Hp;
+    f32x4 s = {0, 0, 0, 0};
     int g = q;
-    for (; g + 16 < G; g += 32) {
-        s0 += partial[(int64_t)g * n + idx];
-        s1 += partial[(int64_t)(g + 16) * n + idx];
+    for (; g + 15 * 16 < G; g += 256) {
+        f32x4 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = *reinterpret_cast<const f32x4*>(partial + (int64_t)(g + 16 * e) * n + idx);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s = s + v[e];
     }
-    if (g < G) s0 += partial[(int64_t)g * n + idx];
-    red[q][o] = s0 + s1;
+    for (; g < G; g += 16) s = s + *reinterpret_cast<const f32x4*>(partial + (int64_t)g * n + idx);
+    red[q][o] = s;
     __syncthreads();
     if (q == 0) {
-        float z = 0.f;
+        f32x4 z = red[0][o];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) z += red[j][o];
-        float a = elu_f(z + bias);
-        a1[idx] = a;
-        if (mask) a1_drop[idx] = a * keep;
+        for (int j = 1; j < 16; ++j) z = z + red[j][o];
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + idx % Hp);
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = elu_f(z[e] + bias[e]);
+        *reinterpret_cast<f32x4*>(a1 + idx) = a;
+        if (mask) {
+            const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mask + idx);
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = ((m4 >> (8 * e)) & 255u) ? a[e] * keep_scale : 0.f;
+            *reinterpret_cast<f32x4*>(a1_drop + idx) = d;
+        }
     }
 }
 
@@ -781,7 +790,7 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
     NHT_SWITCH(nht, LAUNCH_FWD)
 #undef LAUNCH_FWD
     LOC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3(32 * d->Hp / 64), dim3(1024), 0, (hipStream_t)stream, partial, grid,
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(32 * d->Hp / 64), dim3(256), 0, (hipStream_t)stream, partial, grid,
                        32, d->Hp, b1, a1, a1_drop, mask, keep_scale);
     LOC_CHECK_LAUNCH();
     return 0;
@@ -789,7 +798,7 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
 
 // reduction of the large-M forward (l1_rows.hip): rows_p rows, no dropout
 int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const float* b1, float* a1, void* stream) {
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3(rows_p * Hp / 64), dim3(1024), 0, (hipStream_t)stream, partial, G,
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(rows_p * Hp / 64), dim3(256), 0, (hipStream_t)stream, partial, G,
                        rows_p, Hp, b1, a1, (float*)nullptr, (const uint8_t*)nullptr, 1.f);
     LOC_CHECK_LAUNCH();
     return 0;
