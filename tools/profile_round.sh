@@ -13,6 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
+# HBM traffic first: bench.py reports roofline.traffic from profiles/<tag>_pmc_traffic.json when its source hash matches
+bash $R/tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1
+cp $O/pmc_traffic.json $O/${TAG}_pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
 cd $R
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 python3 bench.py --steps 50 --warmup 5 --replicates-per-gpu 2 --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_replicates2.json 2>> $O/${TAG}_bench_default.err
@@ -21,8 +25,6 @@ cd /tmp
 rm -rf $O/prof_kt
 rocprofv3 --kernel-trace --stats -d $O/prof_kt -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2> $O/prof_kt.err
 cp $O/prof_kt/k_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
-bash $R/tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1
-cp $O/pmc_traffic.json $O/${TAG}_pmc_traffic.json
 bash $R/tools/gemm_pmc.sh > $O/gemm_pmc.log 2>&1
 cp $O/gemm_pmc.json $O/${TAG}_gemm_pmc.json
 rm -rf $O/gemm_kt
