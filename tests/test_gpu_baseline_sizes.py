@@ -216,3 +216,25 @@ def test_config4_bootstrap_gather_and_step_at_500k_snps():
     mask_np = (rng.random((32, WIDTH)) >= DROP).astype(np.uint8)
     m, v = O.zeros_like_trainable(p), O.zeros_like_trainable(p)
     _step_check(net, x, y, p, m, v, idx, 1, mask_np)      # p is updated in place: it is not needed afterwards
+
+
+def test_config4_many_row_gemm_at_500k_snps():
+    """The image + GEMM path of a many-row predict at configs[4]'s width (K = 500,000: 7,813 SNP blocks padded to
+    7,814, 3,907 pairs over 32 groups, 0.77 GB of three-piece weight image): 1,200 rows drawn with repeats from a
+    160-row matrix, checked against the fp64 forward on 96 of them (first, last and random rows)."""
+    from tests.test_gpu_gemm import _a1_reference, run_gemm
+    n_mat, K, n = 160, 500_000, 1200
+    rng = np.random.default_rng(45)
+    af = rng.beta(0.4, 0.9, K).clip(0.02, 0.98)
+    x = (rng.random((n_mat, K), dtype=np.float32) < af).astype(np.uint8)
+    x += (rng.random((n_mat, K), dtype=np.float32) < af).astype(np.uint8)
+    y = rng.normal(0, 1, (n_mat, 2))
+    p = randomize_params(O.init_params(K, WIDTH, NLAYERS, rng), rng)
+    net = build_net(x, y, p, drop_p=DROP)
+    rows = rng.integers(0, n_mat, n).astype(np.int32)
+    a1 = run_gemm(net, torch.from_numpy(rows).cuda(), n, 3)
+    check = np.unique(np.concatenate([[0, 1, 127, 128, n - 1], rng.choice(n, 91, replace=False)]))
+    ref, z = _a1_reference(p, x[rows[check]])
+    err = np.abs(a1[check, :WIDTH] - ref).max()
+    assert err < 5e-5, err                                   # exact products, fp32 accumulation over 500k terms
+
