@@ -15,7 +15,7 @@ against oracle.train_step / oracle.predict in float32 and float64.  A report (ma
 stdout and, with --out, the Keras-side tensors go to an .npz that tests/test_golden.py-style fixtures can be built
 from (tests/golden/keras_*.npz would then pin the oracle: DESIGN.md §2 "parity unpinned" could be lifted).
 
-    python tools/keras_crosscheck.py [--snps 300] [--width 32] [--nlayers 4] [--steps 5] [--out keras_vectors.npz]
+    python tests/keras_crosscheck.py [--snps 300] [--width 32] [--nlayers 4] [--steps 5] [--out keras_vectors.npz]
 """
 import argparse
 import importlib.util
