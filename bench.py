@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32, help="--batch_size of the fit (headline: 32, the reference default)")
     ap.add_argument("--replicates-per-gpu", type=int, default=1, help="independent fits per process on separate streams")
+    ap.add_argument("--nt-mask", type=int, default=0, help="loc_tuning.l1b_nt_mask (cache-policy measurement switch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l1-gemm", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -338,7 +339,8 @@ def main():
                 # every replicate resamples the SNP columns on device (locator.py:648-653)
                 so = np.random.RandomState(1000 + replicate).choice(K, K, replace=True)
                 X = gather_columns(X0, so, K)
-            self.net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=replicate, device=dev)
+            self.net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=replicate, device=dev,
+                                  tuning={"l1b_nt_mask": args.nt_mask} if args.nt_mask else None)
             self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph)
             self.cb = Callbacks(100, 1e-3)
             self.rng = np.random.default_rng(99 + replicate)
