@@ -47,8 +47,8 @@ extern "C" {
 #define LOC_MAX_BATCH 128 /* --batch_size limit: four 32-row blocks per step                        */
 #define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
-#define LOC_PREDICT_CHUNK 4096 /* rows per large-M launch inside loc_predict (more rows per launch = fewer SNP
-                                  groups = less partial-sum traffic: 0.135 -> 0.154 of bf16 peak from 1024 to 4096) */
+#define LOC_PREDICT_CHUNK 4096 /* rows per large-M launch inside loc_predict: 4096, not 1024 (more rows per launch =
+                                  fewer SNP groups = less partial-sum traffic: 0.135 -> 0.154 of bf16 peak at 3 pieces) */
 #define LOC_ROWS_BLOCKS 256    /* 128-row tiles the large-M scratch is sized for (one workgroup per CU)   */
 
 typedef struct loc_dims {
@@ -118,12 +118,22 @@ typedef struct loc_net {
     int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
                                 32-row fp32-MFMA kernel for every block of rows                          */
-    void* l1_image;          /* optional: loc_l1_image_bytes(d, pieces) bytes of scratch.  When set, loc_predict over
-                                at least LOC_GEMM_MIN_ROWS(pieces) rows converts W1 once per call (loc_l1_image_build) and
-                                runs every row chunk through loc_l1_forward_gemm; NULL keeps loc_l1_forward_rows */
+    void* l1_image;          /* optional: loc_l1_image_bytes(d, pieces) / loc_l1_image_i8_bytes(d, digits) bytes of
+                                scratch.  When set, loc_predict over at least LOC_GEMM_MIN_ROWS(pieces) /
+                                LOC_GEMM_I8_MIN_ROWS(digits) rows converts W1 once per call (loc_l1_image_build /
+                                loc_l1_image_i8_build) and runs every row chunk through loc_l1_forward_gemm /
+                                loc_l1_forward_gemm_i8; NULL keeps loc_l1_forward_rows */
     int64_t l1_image_bytes;
+    int x_max;               /* largest genotype value in X (loc_genotype_max), 0 = not known.  The int8 GEMM needs
+                                1 <= x_max <= 127; otherwise many-row predicts take the bf16 pieces above          */
+    int predict_digits;      /* int8 digit planes per weight in the many-row inference forward: 3 = 24-bit fixed point
+                                against each unit's largest weight (exact to fp32 accumulation; default when 0),
+                                2 = 16-bit fixed point (fast), -1 = never (bf16 pieces only)                        */
     loc_tuning tune;
 } loc_net;
+/* Rows from which the int8 image + GEMM beats the in-loop-conversion bf16x3 kernel including its once-per-call max pass
+ * and conversion (K = 100,000, profiles/r03_gemm_bench.json). */
+#define LOC_GEMM_I8_MIN_ROWS(digits) 512
 /* Rows from which image + GEMM beats the in-loop-conversion kernel INCLUDING the once-per-call conversion, measured at
  * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 51 / 30 us plus
  * 60 + 0.095 / 20 + 0.036 us per row). */
@@ -163,6 +173,9 @@ int loc_dropout_mask_fill(uint8_t* mask, int64_t n, float p, uint64_t seed, uint
 /* Bootstrap resample of SNP columns (locator.py:648-653): dst[r][j] = src[r][site_order[j]]. */
 int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const int32_t* site_order, int K,
                        uint8_t* dst, int64_t dst_pitch, int n_rows, void* stream);
+/* out[0] = max(out[0], largest byte of X[0..n_rows)[0..K)) (uint32, zero it first): which number formats can carry the
+ * genotypes exactly (int8 needs <= 127). */
+int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, int K, uint32_t* out, void* stream);
 /* Row-major (K x H, Keras) <-> swizzled W1S, on device. */
 int loc_w1_swizzle(const float* w_kh, int K, int H, float* w1s, int Kp, int Hp, void* stream);
 int loc_w1_unswizzle(const float* w1s, int Kp, int Hp, float* w_kh, int K, int H, void* stream);
@@ -218,6 +231,20 @@ int loc_l1_image_build(const loc_dims* d, const float* scale_shift, const float*
 int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                         const void* image, int pieces, const float* b1, float* partial, int64_t partial_floats,
                         float* a1, int target_blocks, void* stream);
+/* The same contraction on the INT8 matrix pipe (l1_gemm_i8.hip), for genotypes known to lie in 0..127 (x_max): a
+ * genotype is an int8 as it stands, so the row operand is never widened; each weight s_k*W1[k][h] is carried as
+ * `digits` base-256 signed digits of a fixed-point number scaled per unit by a power of two chosen from the unit's
+ * largest weight (loc_l1_image_i8_build runs the max pass, then writes the digit planes and the shift term).  Products and
+ * sums are exact integers: 3 digits = 24 bits against the unit's largest weight (no worse than fp32 accumulation
+ * rounding), 2 digits = 16 bits.  Refuses x_max outside 1..127 and SNP groups long enough to overflow int32
+ * (x_max * 128 * SNPs per group >= 2^31).  Other arguments as loc_l1_forward_gemm. */
+int loc_l1_gemm_i8_supported(int Hp, int digits);
+int64_t loc_l1_image_i8_bytes(const loc_dims* d, int digits);
+int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
+                          void* stream);
+int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
+                           const void* image, int digits, int x_max, const float* b1, float* partial,
+                           int64_t partial_floats, float* a1, int target_blocks, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats

@@ -39,7 +39,8 @@ class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
                 ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
-                ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("tune", Tuning)]
+                ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("x_max", C.c_int), ("predict_digits", C.c_int),
+                ("tune", Tuning)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -68,6 +69,12 @@ SIGNATURES = {
     "loc_l1_image_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_l1_forward_gemm": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, vp, vp, C.c_int64, vp,
                                       C.c_int, vp]),
+    "loc_l1_gemm_i8_supported": (C.c_int, [C.c_int, C.c_int]),
+    "loc_l1_image_i8_bytes": (C.c_int64, [C.POINTER(Dims), C.c_int]),
+    "loc_l1_image_i8_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
+    "loc_l1_forward_gemm_i8": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp, vp,
+                                         C.c_int64, vp, C.c_int, vp]),
+    "loc_genotype_max": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     "loc_l1_backward_adam_main": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(Tuning), vp]),
     "loc_l1_backward_adam": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp,

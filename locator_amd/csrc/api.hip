@@ -217,20 +217,31 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,
                                  w.bn4, stream));
     const int pieces = net->predict_pieces == 0 ? 3 : net->predict_pieces;
+    const int digits = net->predict_digits == 0 ? 3 : net->predict_digits;
     if (n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) {
-        // large-M layer 1 on the bf16 matrix pipe, then ONE row-parallel stack launch per chunk.  Many rows: the
-        // weights are converted once into the caller's image buffer and every chunk runs the pure-MFMA GEMM
-        const bool gemm = n >= LOC_GEMM_MIN_ROWS(pieces) && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
+        // large-M layer 1 on the matrix pipe, then ONE row-parallel stack launch per chunk.  Many rows: the weights are
+        // converted once into the caller's image buffer and every chunk runs a pure-MFMA GEMM - on the int8 pipe when
+        // the genotypes are known to fit (x_max <= 127) and no SNP group can overflow int32, else on bf16 pieces
+        const int64_t snps_max = (int64_t)d->Kp + 256;      // one SNP group at most: the whole K range
+        const bool i8 = digits > 0 && net->x_max >= 1 && net->x_max <= 127 && n >= LOC_GEMM_I8_MIN_ROWS(digits) &&
+                        net->l1_image && loc_l1_gemm_i8_supported(Hp, digits) &&
+                        net->l1_image_bytes >= loc_l1_image_i8_bytes(d, digits) &&
+                        (int64_t)net->x_max * 128 * snps_max < ((int64_t)1 << 31);
+        const bool gemm = !i8 && n >= LOC_GEMM_MIN_ROWS(pieces) && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
                           net->l1_image_bytes >= loc_l1_image_bytes(d, pieces);
+        if (i8) TRY(loc_l1_image_i8_build(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
         if (gemm) TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
-            if (gemm)
+            if (i8)
+                TRY(loc_l1_forward_gemm_i8(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, digits, net->x_max,
+                                           P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, stream));
+            else if (gemm)
                 TRY(loc_l1_forward_gemm(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, pieces, P + lay.b1,
                                         w.partial, w.partial_floats, w.a1_rows, 0, stream));
             else
-            TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows + c0, nc, d, w.bn4, P + lay.w1, P + lay.b1,
-                                    w.partial, w.partial_floats, w.a1_rows, pieces, 0, &net->tune, stream));
+                TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows + c0, nc, d, w.bn4, P + lay.w1, P + lay.b1,
+                                        w.partial, w.partial_floats, w.a1_rows, pieces, 0, &net->tune, stream));
             TRY(loc_stack_forward_eval(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
                                        P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
                                        with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,

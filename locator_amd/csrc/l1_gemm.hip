@@ -434,7 +434,19 @@ extern "C" int loc_l1_image_build(const loc_dims* d, const float* scale_shift, c
         default: hipLaunchKernelGGL(l1_image_kernel<3>, dim3(nkt), dim3(GM_HP), 0, st, w1s, scale_shift, d->Kp, tiles, cpart); break;
     }
     LOC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l1_image_cvec_kernel, dim3(GM_HP / 64, 8), dim3(1024), 0, st, cpart, nkt, cvec);
+    return gm_launch_cvec(cpart, nkt, cvec, stream);
+}
+
+// shared with l1_gemm_i8.hip (kernels are launched from the translation unit that defines them)
+int gm_launch_cvec(const float* cpart, int nkt64, float* cvec8, void* stream) {
+    hipLaunchKernelGGL(l1_image_cvec_kernel, dim3(GM_HP / 64, 8), dim3(1024), 0, (hipStream_t)stream, cpart, nkt64, cvec8);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+int gm_launch_reduce(const float* partial, int G, int64_t MH, const float* cvec8, const float* b1, float* a1,
+                     void* stream) {
+    hipLaunchKernelGGL(l1_gemm_reduce_kernel, dim3((unsigned)(MH / 256)), dim3(256), 0, (hipStream_t)stream, partial, G,
+                       MH, cvec8, b1, a1);
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -461,7 +473,10 @@ extern "C" int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int3
         loc_set_error("loc_l1_forward_gemm: width %d / %d pieces unsupported", d->Hp, pieces);
         return -1;
     }
-    if (d->Kp < 16 || x_pitch % 16) { loc_set_error("loc_l1_forward_gemm: needs Kp >= 16 and a 16-byte row pitch"); return -1; }
+    if (d->Kp < 16 || d->Kp % 16 || x_pitch % 16 || x_pitch < d->Kp || ((uintptr_t)X & 15)) {
+        loc_set_error("loc_l1_forward_gemm: needs a 16-byte aligned X, Kp %% 16 == 0 and a 16-byte row pitch >= Kp");
+        return -1;
+    }
     const int nkt = gm_nkt64(d);
     const int n_mt = (n + GM_BM - 1) / GM_BM, Mp = n_mt * GM_BM;
     if (target_blocks < 1) target_blocks = 256;
@@ -489,8 +504,5 @@ extern "C" int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int3
     }
 #undef GM_LAUNCH
     LOC_CHECK_LAUNCH();
-    const int64_t MH = (int64_t)Mp * GM_HP;
-    hipLaunchKernelGGL(l1_gemm_reduce_kernel, dim3((unsigned)(MH / 256)), dim3(256), 0, st, partial, G, MH, cvec, b1, a1);
-    LOC_CHECK_LAUNCH();
-    return 0;
+    return gm_launch_reduce(partial, G, (int64_t)Mp * GM_HP, cvec, b1, a1, stream);
 }

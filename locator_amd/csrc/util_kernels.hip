@@ -105,6 +105,36 @@ extern "C" int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const i
     return 0;
 }
 
+// largest genotype byte: 16 bytes per thread and step, wave maximum by shuffles, one atomicMax per wave
+__global__ __launch_bounds__(256) void genotype_max_kernel(const uint8_t* __restrict__ X, int64_t pitch, int K,
+                                                           uint32_t* __restrict__ out) {
+    const uint8_t* row = X + (int64_t)blockIdx.y * pitch;
+    uint32_t m = 0;
+    const int K16 = K & ~15;
+    for (int k = (blockIdx.x * 256 + threadIdx.x) * 16; k < K16; k += gridDim.x * 256 * 16) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t a = v[d];
+            m = max(m, max(max(a & 255u, (a >> 8) & 255u), max((a >> 16) & 255u, a >> 24)));
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int k = K16 + threadIdx.x; k < K; k += 256) m = max(m, (uint32_t)row[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+extern "C" int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, int K, uint32_t* out, void* stream) {
+    if (n_rows <= 0 || K <= 0) return 0;
+    if (((uintptr_t)X & 15) || x_pitch % 16) { loc_set_error("loc_genotype_max: needs a 16-byte aligned X and row pitch"); return -1; }
+    const int gx = K >= 65536 ? 8 : 1;
+    hipLaunchKernelGGL(genotype_max_kernel, dim3(gx, n_rows), dim3(256), 0, (hipStream_t)stream, X, x_pitch, K, out);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int loc_w1_swizzle(const float* w_kh, int K, int H, float* w1s, int Kp, int Hp, void* stream) {
     int64_t n = (int64_t)Kp * Hp;
     hipLaunchKernelGGL(w1_swizzle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kh,

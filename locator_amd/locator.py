@@ -18,7 +18,7 @@ Deliberate, documented deviations:
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 128 rows (the reference default is 32; 33..128 needs a --width that pads to 64,
     128 or 256 and --nlayers >= 4 with dropout), --nlayers must be >= 2 and --width <= 512;
-  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed / --load_weights / --predict_pieces (recorded at
+  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """
 from __future__ import annotations
@@ -84,9 +84,14 @@ def build_parser():
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
     p.add_argument("--load_weights", default=None, type=str,
                    help="a .weights.npz written by --keep_weights: skip training and predict with these weights")
-    p.add_argument("--predict_pieces", default=3, type=int,
-                   help="bf16 pieces per first-layer weight in many-row predictions: 3 = fp32-exact products "
-                        "(default), 1 or 2 = faster, approximate")
+    p.add_argument("--predict_mode", default="exact", choices=("exact", "fast"),
+                   help="first-layer arithmetic of many-row predictions on the int8 matrix pipe: exact = 24-bit fixed "
+                        "point per weight (as accurate as fp32 accumulation; default), fast = 16-bit (predictions "
+                        "within 1e-3 relative, tests/test_gpu_baseline_sizes.py)")
+    p.add_argument("--predict_pieces", default=None, type=int,
+                   help="force the bf16 matrix pipe with this many pieces per first-layer weight instead: 3 = "
+                        "fp32-exact products, 1 or 2 = faster, approximate (default: bf16 x 3 only where the int8 "
+                        "form does not apply - few rows, genotype values above 127)")
     p.add_argument("--net_seed", default=None, type=int,
                    help="seed of weight init / shuffling / dropout (the reference leaves these unseeded); "
                         "default: --seed, else entropy")
@@ -219,7 +224,7 @@ class Model:
         from .net import LocatorNet
         self.net = LocatorNet(X, Y, self.n_snps, self.width, self.nlayers, self.dropout_prop, seed=self.seed,
                               replicate=self.replicate, device=self.device,
-                              predict_pieces=getattr(args, "predict_pieces", 3))
+                              **predict_settings(args))
         return self.net
 
     def predict(self, gen):
@@ -246,6 +251,14 @@ class Model:
 
     def weights_dict(self):
         return self.net.export_params()
+
+
+def predict_settings(a):
+    """--predict_mode / --predict_pieces -> LocatorNet(predict_pieces=, predict_digits=)."""
+    forced = getattr(a, "predict_pieces", None)
+    if forced is not None:
+        return {"predict_pieces": int(forced), "predict_digits": -1}
+    return {"predict_pieces": 3, "predict_digits": 2 if getattr(a, "predict_mode", "exact") == "fast" else 3}
 
 
 def load_network(traingen, dropout_prop, replicate=0, device="cuda:0"):
@@ -280,6 +293,8 @@ def save_weights(path, w):
     flat = {"gamma": w["gamma"], "beta": w["beta"], "moving_mean": w["mov_mean"], "moving_variance": w["mov_var"]}
     for i, (k, b) in enumerate(zip(w["W"], w["b"])):
         flat[f"dense_{i}_kernel"], flat[f"dense_{i}_bias"] = k, b
+    flat["n_snps"], flat["width"], flat["nlayers"] = (np.int64(w["W"][0].shape[0]), np.int64(w["W"][0].shape[1]),
+                                                      np.int64(len(w["W"]) - 2))
     _write_atomic(path, lambda fh: np.savez(fh, **flat), mode="wb")
 
 
@@ -322,7 +337,11 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
     model._build(X, Y)
     model.n_train, model.n_val = ntr, nva
     if getattr(args, "load_weights", None):
-        model.net.import_params(read_weights(args.load_weights))     # predict-only: nothing is trained
+        try:
+            model.net.import_params(read_weights(args.load_weights))     # predict-only: nothing is trained
+        except (ValueError, KeyError) as e:
+            raise SystemExit(f"--load_weights {args.load_weights}: {e} - the file must come from a run with the same "
+                             "genotypes and filters (--min_mac, --max_SNPs, --impute_missing), --width and --nlayers")
         history = History()
     else:
         history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,

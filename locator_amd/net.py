@@ -20,6 +20,7 @@ LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
 LOC_GEMM_MIN_ROWS = {3: 1152, 2: 768, 1: 640}  # include/locator_hip.h, by bf16 pieces
+LOC_GEMM_I8_MIN_ROWS = 512                     # include/locator_hip.h: int8 image + GEMM
 
 
 def _ptr(t):
@@ -51,10 +52,13 @@ class LocatorNet:
     Adam, Euclidean loss — the model of locator.py:311-327, resident on one GPU."""
 
     def __init__(self, X, Y, K, width=256, nlayers=10, dropout_prop=0.25, seed=0, replicate=0, device="cuda:0",
-                 predict_pieces=3, tuning=None):
-        """predict_pieces: bf16 pieces per weight in the large-M inference forward (3 = exact fp32 products; 1 or 2
-        trade accuracy for speed, -1 keeps every row block on the 32-row fp32-MFMA kernel).  tuning: dict of
-        loc_tuning fields (include/locator_hip.h) - speed hints and measurement switches, never results."""
+                 predict_pieces=3, predict_digits=3, tuning=None):
+        """predict_digits: int8 digit planes per weight in the many-row inference forward (3 = 24-bit fixed point against
+        each unit's largest weight, exact to fp32 accumulation; 2 = 16-bit, faster; -1 = never use the int8 pipe).
+        predict_pieces: bf16 pieces per weight where the int8 GEMM does not apply - few rows, genotypes above 127 -
+        (3 = exact fp32 products; 1 or 2 trade accuracy for speed, -1 keeps every row block on the 32-row fp32-MFMA
+        kernel).  tuning: dict of loc_tuning fields (include/locator_hip.h) - speed hints and measurement switches,
+        never results."""
         require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -87,6 +91,7 @@ class LocatorNet:
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
         self.predict_pieces = int(predict_pieces)
+        self.predict_digits = int(predict_digits)
         self.tuning = _lib.Tuning(**{k: int(v) for k, v in (tuning or {}).items()})
         self.l1_image = None               # bf16 image of s_k*W1 for many-row predicts (allocated on first use)
         self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
@@ -122,6 +127,8 @@ class LocatorNet:
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         n.slot_rows = self.slot_rows
         n.predict_pieces = self.predict_pieces
+        n.predict_digits = self.predict_digits
+        n.x_max = int(getattr(self.X, "loc_x_max", 0))      # set by genotype_max() on the tensor object itself
         if self.l1_image is not None:
             n.l1_image, n.l1_image_bytes = self.l1_image.data_ptr(), self.l1_image.numel()
         n.tune = self.tuning
@@ -216,7 +223,26 @@ class LocatorNet:
             flat[lay.mov_mean:lay.mov_mean + d.K] = f32(p["mov_mean"])
             flat[lay.mov_var:lay.mov_var + d.K] = f32(p["mov_var"])
 
+    def check_params(self, p, with_moving=True):
+        """Shapes of an oracle-format parameter dict against this net, BEFORE any device call: the swizzle kernel
+        reads W[0] as K x H whatever the file holds, so a file from another SNP count / --width / --nlayers would be
+        an out-of-bounds device read."""
+        d = self.d
+        W, b = list(p["W"]), list(p["b"])
+        if len(W) != d.L + 2 or len(b) != d.L + 2:
+            raise ValueError(f"weights hold {len(W)} Dense layers; this network has {d.L + 2} "
+                             f"(--nlayers {d.L} + Dense(2) + Dense(2))")
+        want = [(d.K, d.H)] + [(d.H, d.H)] * (d.L - 1) + [(d.H, 2), (2, 2)]
+        for i, (w, bi, shp) in enumerate(zip(W, b, want)):
+            if tuple(np.shape(w)) != shp or tuple(np.shape(bi)) != (shp[1],):
+                raise ValueError(f"dense_{i}: kernel {tuple(np.shape(w))} / bias {tuple(np.shape(bi))} in the weights, "
+                                 f"this network needs {shp} / ({shp[1]},) (SNPs {d.K}, --width {d.H}, --nlayers {d.L})")
+        for k in ("gamma", "beta") + (("mov_mean", "mov_var") if with_moving else ()):
+            if tuple(np.shape(p[k])) != (d.K,):
+                raise ValueError(f"{k}: length {np.shape(p[k])} in the weights, this network has {d.K} SNPs")
+
     def import_params(self, p):
+        self.check_params(p)
         self._import_flat(self.params, p)
         self.refresh_transposed()
 
@@ -243,15 +269,35 @@ class LocatorNet:
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
-        if (self.predict_pieces > 0 and n >= LOC_GEMM_MIN_ROWS.get(self.predict_pieces, 1 << 30) and self.l1_image is None
-                and self.lib.loc_l1_gemm_supported(self.d.Hp, self.predict_pieces)):
+        lib, d = self.lib, self.d
+        use_i8 = (self.predict_pieces > 0 and self.predict_digits > 0 and n >= LOC_GEMM_I8_MIN_ROWS
+                  and lib.loc_l1_gemm_i8_supported(d.Hp, self.predict_digits))
+        if use_i8 and self.genotype_max() > 127:
+            use_i8 = False
+        need = 0
+        if use_i8:
+            need = lib.loc_l1_image_i8_bytes(C.byref(d), self.predict_digits)
+        elif (self.predict_pieces > 0 and n >= LOC_GEMM_MIN_ROWS.get(self.predict_pieces, 1 << 30)
+              and lib.loc_l1_gemm_supported(d.Hp, self.predict_pieces)):
+            need = lib.loc_l1_image_bytes(C.byref(d), self.predict_pieces)
+        if need and (self.l1_image is None or self.l1_image.numel() < need):
             # many rows: W1 is converted once per call into this buffer (include/locator_hip.h, loc_net.l1_image)
-            self.l1_image = torch.empty(self.lib.loc_l1_image_bytes(C.byref(self.d), self.predict_pieces),
-                                        dtype=torch.uint8, device=self.device)
+            self.l1_image = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._net = None
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
                                         _ptr(dist), _stream()), "loc_predict")
+
+    def genotype_max(self):
+        """Largest genotype value of the current X (one streaming pass, cached per matrix): decides whether the rows
+        are int8 operands as they stand (include/locator_hip.h, loc_net.x_max)."""
+        if getattr(self.X, "loc_x_max", None) is None:
+            out = torch.zeros(1, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.loc_genotype_max(self.X.data_ptr(), self.X.stride(0), self.X.shape[0], self.d.K,
+                                                 out.data_ptr(), _stream()), "loc_genotype_max")
+            self.X.loc_x_max = int(out.item())     # X is never modified in place (resamples make new tensors)
+            self._net = None
+        return self.X.loc_x_max
 
     def fill_dropout_masks(self, mask_buf, n, offset):
         _lib.check(self.lib.loc_dropout_mask_fill(_ptr(mask_buf), int(n), self.drop_p,

@@ -97,24 +97,46 @@ def test_config2_three_consecutive_steps(config2):
         _step_check(net, x, y, pr, m, v, idx, t, mask_np, w_tol=2e-5)
 
 
-@pytest.mark.parametrize("pieces,reps", [(3, 1), (3, 3), (1, 1)])
-def test_config2_predict_all_rows(config2, pieces, reps):
-    """loc_predict over all 1000 rows, and over 3000 (every row three times: past LOC_GEMM_MIN_ROWS(3) = 1152, so the
-    first layer runs as image + GEMM, converted once for three 1024-row chunks), vs oracle.predict, plus the per-row
-    validation distances.  One bf16 piece (1000 rows >= 640: image + GEMM too): 2e-2."""
+PREDICT_MODES = {   # name: (LocatorNet settings, absolute bar on z-scored predictions, rows from which an image is built)
+    "int8x3": ({"predict_digits": 3}, 2e-5, 512),
+    "int8x2": ({"predict_digits": 2}, None, 512),
+    "bf16x3": ({"predict_digits": -1, "predict_pieces": 3}, 2e-5, 1152),
+    "bf16x2": ({"predict_digits": -1, "predict_pieces": 2}, None, 768),
+    "bf16x1": ({"predict_digits": -1, "predict_pieces": 1}, None, 640),
+}
+# north_star: "predlocs within 1e-3 relative of the Keras reference".  Every many-row mode the bench quotes against the
+# MFMA target must meet it here, at the metric's K; bf16 x 1 does NOT (it is held to 2e-2 and is not quoted).
+NORTH_STAR_REL = 1e-3
+
+
+@pytest.mark.parametrize("mode,reps", [("int8x3", 1), ("int8x3", 5), ("int8x2", 1), ("int8x2", 5), ("bf16x3", 1),
+                                       ("bf16x3", 3), ("bf16x2", 1), ("bf16x1", 1)])
+def test_config2_predict_all_rows(config2, mode, reps):
+    """loc_predict over all 1000 rows, and over 3000 / 5000 (every row several times: more than one LOC_PREDICT_CHUNK of
+    4096 rows at 5000, the image converted once for both chunks), vs oracle.predict, plus the per-row validation
+    distances.  The deviation of the predictions relative to the largest prediction is printed per mode and asserted
+    against the north_star bound for every mode except plain bf16 weights."""
     x, y, p, train, test, pred = config2
-    net = build_net(x, y, p, drop_p=DROP, predict_pieces=pieces)
+    kw, tol_abs, min_rows = PREDICT_MODES[mode]
+    net = build_net(x, y, p, drop_p=DROP, **kw)
     n = x.shape[0] * reps
-    tol = 2e-5 if pieces == 3 else 2e-2
     rows = torch.from_numpy((np.random.default_rng(3).permutation(n) % x.shape[0]).astype(np.int32)).cuda()
     yhat, dist = torch.zeros((n, 2), device="cuda"), torch.zeros(n, device="cuda")
     net.predict_rows(rows, n, yhat, dist)
     torch.cuda.synchronize()
-    assert (net.l1_image is not None) == (n >= {3: 1152, 1: 640}[pieces])
+    assert (net.l1_image is not None) == (n >= min_rows)
     r = rows.cpu().numpy()
     ref = O.predict(p, x[r], batch=250)
-    assert maxerr(yhat.cpu().numpy(), ref) < tol, maxerr(yhat.cpu().numpy(), ref)
-    assert maxerr(dist.cpu().numpy(), O.euclid(ref, y[r])) < tol
+    err = maxerr(yhat.cpu().numpy(), ref)
+    rel = err / float(np.abs(ref).max())
+    print(f"predict mode {mode}, {n} rows: max |dev| {err:.3e}, relative to max |pred| {rel:.3e}")
+    if mode == "bf16x1":
+        assert err < 2e-2 and rel > 1e-4, (err, rel)            # outside the north_star tolerance: never quoted
+    else:
+        assert rel <= NORTH_STAR_REL, (mode, err, rel)
+    if tol_abs is not None:
+        assert err < tol_abs, err
+        assert maxerr(dist.cpu().numpy(), O.euclid(ref, y[r])) < tol_abs
 
 
 def test_config2_two_epoch_graph_fit_matches_oracle_fit(config2):

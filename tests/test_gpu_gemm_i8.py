@@ -1,0 +1,236 @@
+"""GPU parity tests of the int8 large-M layer-1 GEMM (loc_l1_image_i8_build + loc_l1_forward_gemm_i8,
+locator_amd/csrc/l1_gemm_i8.hip) against the fp64 oracle forward (oracle/locator_oracle.py, inference mode).
+
+Reference lines: model.predict, /root/reference/locator/locator.py:414, :441; --jacknife, :683-747.
+Tolerances on a1 = ELU(z1), |z1| = O(1):
+  3 digits : 24-bit fixed point against each unit's largest weight, exact integer accumulation -> 2e-5 absolute, the
+             bar of the exactly-split bf16 x 3 kernel (tests/test_gpu_gemm.py) and of the fp32-MFMA kernel
+  2 digits : 16-bit fixed point -> each weight is off by at most delta_h / 2 = max_k|w'| 2^-16 (asserted from the
+             decoded image); on z1 that is a random walk over the non-zero genotypes of a row
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import build_net, make_problem, maxerr
+
+pytestmark = pytest.mark.gpu
+
+G8_HP, G8_TILE = 256, 16384
+
+
+def _a1_reference(p, x):
+    xh = (x.astype(np.float64) - p["mov_mean"]) / np.sqrt(p["mov_var"] + 1e-3) * p["gamma"] + p["beta"]
+    z = xh @ p["W"][0] + p["b"][0]
+    return np.where(z > 0, z, np.expm1(z)), z
+
+
+def _bn4(net):
+    from locator_amd import _lib
+    d, lay, lib = net.d, net.lay, net.lib
+    P = net.params.data_ptr()
+    bn4 = torch.zeros(4 * d.Kp, device="cuda")
+    _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
+                                            P + 4 * lay.mov_var, bn4.data_ptr(), None))
+    return bn4
+
+
+def build_image(net, digits):
+    from locator_amd import _lib
+    d, lay, lib = net.d, net.lay, net.lib
+    bn4 = _bn4(net)
+    image = torch.zeros(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), net.params.data_ptr() + 4 * lay.w1, digits,
+                                         image.data_ptr(), None), "loc_l1_image_i8_build")
+    torch.cuda.synchronize()
+    return image, bn4
+
+
+def run_gemm_i8(net, rows, n, digits, x_max=2, target_blocks=0, scratch_tiles=256, image=None):
+    from locator_amd import _lib
+    d, lay, lib = net.d, net.lay, net.lib
+    if image is None:
+        image, _ = build_image(net, digits)
+    mp = (n + 127) // 128 * 128
+    partial = torch.empty(scratch_tiles * 128 * d.Hp, device="cuda")
+    a1 = torch.full((mp, d.Hp), float("nan"), device="cuda")
+    _lib.check(lib.loc_l1_forward_gemm_i8(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n, C.byref(d),
+                                          image.data_ptr(), digits, x_max, net.params.data_ptr() + 4 * lay.b1,
+                                          partial.data_ptr(), partial.numel(), a1.data_ptr(), target_blocks, None),
+               "loc_l1_forward_gemm_i8")
+    torch.cuda.synchronize()
+    return a1.cpu().numpy()
+
+
+def decode_image(image, d, digits):
+    """(delta[Hp], q[K-padded][Hp]) from the device image: the layout documented in l1_gemm_i8.hip."""
+    raw = image.cpu().numpy()
+    nkt = ((d.Kp + 63) // 64 + 1) & ~1
+    delta = raw[8 * G8_HP * 4: 9 * G8_HP * 4].view(np.float32).copy()
+    tiles_off = (10 * G8_HP * 4 + nkt * G8_HP * 4 + 1023) // 1024 * 1024
+    t = raw[tiles_off: tiles_off + nkt * digits * G8_TILE].view(np.int8).reshape(nkt, digits, 4, G8_HP, 16)
+    q = np.zeros((nkt, 4, G8_HP, 16), np.int64)
+    for p in range(digits):
+        q = q * 256 + t[:, p].astype(np.int64)
+    return delta, q.transpose(0, 1, 3, 2).reshape(nkt * 64, G8_HP)          # [k][unit]
+
+
+@pytest.mark.parametrize("digits", [2, 3])
+def test_digit_image_is_the_rounded_fixed_point_weight_bit_for_bit(digits):
+    """q = rint(fp32(s_k W1[k][h]) / delta_h) with delta_h the power of two the max pass picks; every digit in
+    [-128, 127]; the shift term equals sum_k t_k W1[k][h]."""
+    K, width, n = 5830, 256, 64
+    x, y, p, rng = make_problem(n, K, width, 2, seed=digits)
+    p["W"][0][:, 7] = 0.0                                    # an all-zero unit: delta = 1, digits 0
+    p["W"][0][11, 3] *= 40.0                                  # one dominant weight sets that unit's scale
+    net = build_net(x, y, p)
+    image, bn4 = build_image(net, digits)
+    delta, q = decode_image(image, net.d, digits)
+    w = np.zeros((q.shape[0], width), np.float32)
+    w[:K] = p["W"][0].astype(np.float32) * bn4[:K].cpu().numpy()[:, None]
+    lim = {2: 32639, 3: 8355711}[digits]
+    mx = np.abs(w).max(0)
+    assert delta[7] == 1.0 and not q[:, 7].any()
+    live = mx > 0
+    assert np.all(np.log2(delta[:width][live]) % 1 == 0)
+    ratio = mx[live] / delta[:width][live]
+    assert np.all(ratio <= lim) and np.all(ratio > lim / 2 - 1), (ratio.min(), ratio.max())
+    want = np.rint(w.astype(np.float64) / delta[:width].astype(np.float64)).astype(np.int64)
+    assert np.array_equal(q[:, :width], want)
+    assert not q[:, width:].any() and not q[K:].any()
+    cvec = image[:8 * G8_HP * 4].cpu().numpy().view(np.float32).reshape(8, G8_HP).sum(0)
+    shift = bn4[net.d.Kp: net.d.Kp + K].cpu().numpy().astype(np.float64)
+    assert maxerr(cvec[:width], shift @ p["W"][0]) < 2e-5
+
+
+@pytest.mark.parametrize("K,n", [(5830, 450), (64, 1), (97, 130), (4096, 129), (3000, 300), (8192, 1000),
+                                 (100, 128), (32, 5), (20000, 257)])
+def test_three_digits_is_fp32_exact(K, n):
+    """K not a multiple of 64 / 128 (zero tail of the image, a zero tile pads an odd block count), K < one block, row
+    counts around the 128-row tile edge, more row tiles than SNP groups allow at 256 workgroups."""
+    width = 256
+    x, y, p, rng = make_problem(max(n, 8), K, width, 2, seed=K + n)
+    net = build_net(x, y, p)
+    assert net.lib.loc_l1_gemm_i8_supported(net.d.Hp, 3)
+    r = rng.permutation(x.shape[0])[:n].astype(np.int32)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, 3)
+    ref, _ = _a1_reference(p, x[r])
+    assert maxerr(a1[:n, :width], ref) < 2e-5, maxerr(a1[:n, :width], ref)
+    assert np.isfinite(a1).all()
+
+
+def test_genotypes_up_to_127_and_padded_width():
+    """Any int8-representable genotype is exact (x_max = 127 here); width 250 pads to 256 with zero units."""
+    K, n, width = 1000, 200, 250
+    x, y, p, rng = make_problem(n, K, width, 2, seed=3)
+    x = rng.integers(0, 128, x.shape).astype(np.uint8)
+    net = build_net(x, y, p)
+    assert net.genotype_max() == int(x.max()) == 127
+    r = np.arange(n, dtype=np.int32)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, 3, x_max=127)
+    ref, z = _a1_reference(p, x)
+    assert maxerr(a1[:n, :width], ref) < 2e-5 * max(1.0, np.abs(z).max())
+    assert not a1[:n, width:].any()
+
+
+def test_two_digits_error_is_the_quantisation_step():
+    """16-bit fixed point: a1 deviates from the fp64 forward by a random walk of per-weight errors <= delta_h / 2 over
+    the row's non-zero genotypes - bounded here by 6 sigma of that walk, and far below the 1e-2 of plain bf16."""
+    K, width, n = 5830, 256, 200
+    x, y, p, rng = make_problem(n, K, width, 2, seed=2)
+    net = build_net(x, y, p)
+    image, _ = build_image(net, 2)
+    delta, _ = decode_image(image, net.d, 2)
+    r = np.arange(n, dtype=np.int32)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, 2, image=image)
+    ref, z = _a1_reference(p, x[r])
+    err = np.abs(a1[:n, :width] - ref)
+    walk = np.sqrt((x[r].astype(np.float64) ** 2).sum(1))[:, None] * delta[None, :width] / np.sqrt(12.0)
+    assert np.all(err < 6.0 * walk + 2e-5), float((err / (6.0 * walk + 2e-5)).max())
+    assert err.max() < 2e-3 and err.max() > 1e-6, err.max()
+
+
+def test_deterministic_and_independent_of_the_group_split():
+    from tests.test_gpu_gemm import run_gemm
+    K, width, n = 5830, 256, 300
+    x, y, p, rng = make_problem(n, K, width, 2, seed=5)
+    net = build_net(x, y, p)
+    r = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    a = run_gemm_i8(net, r, n, 3)
+    b = run_gemm_i8(net, r, n, 3)
+    assert np.array_equal(a, b)
+    c = run_gemm_i8(net, r, n, 3, target_blocks=24, scratch_tiles=24)      # a different SNP-group split
+    assert maxerr(a[:n], c[:n]) < 5e-6
+    d = run_gemm(net, r, n, 3)                                             # exactly-split bf16 x 3
+    assert maxerr(a[:n], d[:n]) < 1e-5
+
+
+@pytest.mark.parametrize("digits,target_blocks", [(2, 0), (3, 0), (2, 48), (3, 24), (2, 8), (3, 8)])
+def test_every_loop_shape(digits, target_blocks):
+    """The unrolled body holds 6 SNP blocks and a remainder of 2 or 4 follows; the number of SNP groups decides how
+    many blocks a workgroup walks.  K = 20,000 is 313 blocks (odd: one zero tile pads the last pair); 1000 rows at the
+    default 256 workgroups = 32 groups of 8-10 blocks; 48 -> 6 groups of 52-54, 24 -> 3 of 104-106, 8 -> 1 group of all
+    314.  Every row and unit is compared with the fp64 forward."""
+    K, width, n = 20000, 256, 1000
+    x, y, p, rng = make_problem(n, K, width, 2, seed=11 + digits)
+    net = build_net(x, y, p)
+    r = rng.permutation(n).astype(np.int32)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, digits, target_blocks=target_blocks)
+    ref, z = _a1_reference(p, x[r])
+    err = maxerr(a1[:n, :width], ref)
+    assert err < {3: 3e-5, 2: 4e-3}[digits], err
+
+
+def test_rejects_what_it_cannot_do():
+    from locator_amd import _lib
+    x, y, p, rng = make_problem(40, 256, 128, 2, seed=9)
+    net = build_net(x, y, p)
+    assert not net.lib.loc_l1_gemm_i8_supported(128, 3) and not net.lib.loc_l1_gemm_i8_supported(256, 1)
+    assert net.lib.loc_l1_image_i8_bytes(C.byref(net.d), 3) == 0
+    x, y, p, rng = make_problem(300, 256, 256, 2, seed=9)
+    net = build_net(x, y, p)
+    rows = torch.arange(300, dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.LocatorHipError, match="scratch too small"):
+        run_gemm_i8(net, rows, 300, 3, scratch_tiles=1)
+    for bad in (0, 128, 255):
+        with pytest.raises(_lib.LocatorHipError, match="0..127"):
+            run_gemm_i8(net, rows, 300, 3, x_max=bad)
+    # one group over 140,000 SNPs with genotypes up to 127: 127 * 128 * 140,032 > 2^31
+    x, y, p, rng = make_problem(130, 140_000, 256, 2, seed=1)
+    net = build_net(x, y, p)
+    with pytest.raises(_lib.LocatorHipError, match="overflow int32"):
+        run_gemm_i8(net, torch.arange(130, dtype=torch.int32, device="cuda"), 130, 2, x_max=127, target_blocks=2)
+
+
+def test_predict_takes_the_int8_path_only_when_the_genotypes_allow_it():
+    """loc_predict: >= 512 rows of genotypes <= 127 -> int8 image (exact digits by default); a genotype of 200 ->
+    bf16 pieces, same predictions."""
+    from oracle import locator_oracle as O
+    K, width, n = 3000, 256, 1300
+    x, y, p, rng = make_problem(n, K, width, 4, seed=21)
+    ref = O.predict(p, x)
+    outs = {}
+    for name, xx, kw in (("i8", x, {}), ("i8fast", x, {"predict_digits": 2}), ("bf16", x, {"predict_digits": -1})):
+        net = build_net(xx, y, p, **kw)
+        rows = torch.arange(n, dtype=torch.int32, device="cuda")
+        yhat = torch.zeros((n, 2), device="cuda")
+        net.predict_rows(rows, n, yhat)
+        torch.cuda.synchronize()
+        outs[name] = yhat.cpu().numpy()
+        want = {"i8": net.lib.loc_l1_image_i8_bytes(C.byref(net.d), 3), "i8fast": net.lib.loc_l1_image_i8_bytes(C.byref(net.d), 2),
+                "bf16": net.lib.loc_l1_image_bytes(C.byref(net.d), 3)}[name]
+        assert net.l1_image is not None and net.l1_image.numel() == want
+        if name != "bf16":
+            assert net.cnet().x_max == 2
+    assert maxerr(outs["i8"], ref) < 2e-5 and maxerr(outs["bf16"], ref) < 2e-5
+    assert maxerr(outs["i8fast"], ref) < 1e-3 * np.abs(ref).max()
+    x2 = x.copy()
+    x2[5, 17] = 200
+    net = build_net(x2, y, p)
+    yhat = torch.zeros((n, 2), device="cuda")
+    net.predict_rows(torch.arange(n, dtype=torch.int32, device="cuda"), n, yhat)
+    torch.cuda.synchronize()
+    assert net.genotype_max() == 200 and net.l1_image.numel() == net.lib.loc_l1_image_bytes(C.byref(net.d), 3)
+    assert maxerr(yhat.cpu().numpy(), O.predict(p, x2)) < 2e-5

@@ -466,3 +466,29 @@ def test_blosc_zarr_store_round_trip_and_unsupported_codecs(tmp_path):
     bitshuf[2] |= 0x04
     with pytest.raises(ValueError, match="bit-shuffle"):
         G.blosc_decompress(bytes(bitshuf))
+
+
+def test_weights_from_another_network_are_refused_before_any_device_call(tmp_path):
+    """--load_weights / LocatorNet.import_params: a .weights.npz from another SNP count, --width or
+    --nlayers must raise on the host; the swizzle kernel would otherwise read it as K x H."""
+    from locator_amd import _lib
+    from locator_amd.net import LocatorNet
+    rng = np.random.default_rng(0)
+    p = O.init_params(40, 16, 3, rng)
+    path = str(tmp_path / "w.npz")
+    L.save_weights(path, {**p, "mov_mean": p["mov_mean"], "mov_var": p["mov_var"]})
+    z = np.load(path)
+    assert int(z["n_snps"]) == 40 and int(z["width"]) == 16 and int(z["nlayers"]) == 3
+    back = L.read_weights(path)
+    assert len(back["W"]) == 5 and back["W"][0].shape == (40, 16)
+    net = LocatorNet.__new__(LocatorNet)                 # shapes only: no device, no library call
+    net.d = _lib.Dims(K=40, Kp=64, H=16, Hp=32, L=3, n_pre=1)
+    net.check_params(back)
+    for K, H, Lh, what in ((41, 16, 3, "SNPs 41"), (40, 32, 3, "--width 32"), (40, 16, 4, "--nlayers 4")):
+        net.d = _lib.Dims(K=K, Kp=64, H=H, Hp=32, L=Lh, n_pre=Lh // 2)
+        with pytest.raises(ValueError, match=what):
+            net.check_params(back)
+    net.d = _lib.Dims(K=40, Kp=64, H=16, Hp=32, L=3, n_pre=1)
+    bad = dict(back, gamma=np.ones(39))
+    with pytest.raises(ValueError, match="gamma"):
+        net.check_params(bad)

@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--rows", default="1000,450,90")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--blocks", default="0")
-    ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMM (l1_gemm.hip)")
+    ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMMs (l1_gemm.hip, l1_gemm_i8.hip)")
+    ap.add_argument("--i8-only", action="store_true", help="only the int8 GEMM (l1_gemm_i8.hip)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n_max = max(int(r) for r in a.rows.split(","))
@@ -44,7 +45,7 @@ def main():
                                             P + 4 * lay.mov_var, bn4.data_ptr(), None))
     partial = torch.empty(512 * 128 * d.Hp, device=dev)
     out = []
-    for n in ([] if a.gemm_only else [int(r) for r in a.rows.split(",")]):
+    for n in ([] if a.gemm_only or a.i8_only else [int(r) for r in a.rows.split(",")]):
         rows = torch.arange(n, dtype=torch.int32, device=dev)
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for blocks in [int(b) for b in a.blocks.split(",")]:
@@ -76,8 +77,47 @@ def main():
                        "gbs": round(byts / us * 1e-3, 1), "frac_hbm_peak": round(byts / us * 1e-3 / HBM_PEAK_GBS, 4)}
                 print(json.dumps(rec), flush=True)
                 out.append(rec)
-    # image-based GEMM (l1_gemm.hip): conversion once per sweep, then a pure matrix-pipe K loop
+    # int8 image + GEMM (l1_gemm_i8.hip): digits = 3 exact (1.5 bf16-MFMA equivalents per product), 2 fast (1)
     for n in [int(r) for r in a.rows.split(",")]:
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
+        for digits in (3, 2):
+            if not lib.loc_l1_gemm_i8_supported(d.Hp, digits):
+                continue
+            image = torch.empty(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device=dev)
+
+            def prep():
+                _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, digits,
+                                                     image.data_ptr(), None))
+            for blocks in [int(b) for b in a.blocks.split(",")]:
+                def run():
+                    _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
+                                                          image.data_ptr(), digits, 2, P + 4 * lay.b1,
+                                                          partial.data_ptr(), partial.numel(), a1.data_ptr(), blocks,
+                                                          None))
+                t = {}
+                for name, fn in (("prep", prep), ("gemm", run)):
+                    for _ in range(5):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(a.iters):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+                flops = 2.0 * n * a.snps * a.width
+                rec = {"kernel": "int8 image+gemm", "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
+                       "digits": digits, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
+                       "tflops": round(flops / t["gemm"] * 1e-6, 1),
+                       "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "frac_bf16_peak_incl_prep": round(flops / (t["gemm"] + t["prep"]) * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                       "i8_mfma_issue_frac": round(digits * 0.5 * flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4)}
+                print(json.dumps(rec), flush=True)
+                out.append(rec)
+    # image-based GEMM (l1_gemm.hip): conversion once per sweep, then a pure matrix-pipe K loop
+    for n in ([] if a.i8_only else [int(r) for r in a.rows.split(",")]):
         rows = torch.arange(n, dtype=torch.int32, device=dev)
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for pieces in (3, 2, 1):
