@@ -129,6 +129,10 @@ typedef struct loc_net {
     int predict_digits;      /* int8 digit planes per weight in the many-row inference forward: 3 = 24-bit fixed point
                                 against each unit's largest weight (exact to fp32 accumulation; default when 0),
                                 2 = 16-bit fixed point (fast), -1 = never (bf16 pieces only)                        */
+    int l1_image_ready;      /* what l1_image already holds for the CURRENT parameters: 0 = nothing (loc_predict builds what it
+                                needs), otherwise a value loc_predict_image_mode() returned for an earlier loc_predict call
+                                since which neither the parameters nor the BatchNorm statistics changed - the conversion is
+                                then skipped (predict_locs predicts twice with the same weights, locator.py:414, :441) */
     loc_tuning tune;
 } loc_net;
 /* Rows from which the int8 image + GEMM beats the in-loop-conversion bf16x3 kernel including its once-per-call max pass
@@ -342,6 +346,10 @@ float* loc_workspace_bn4(const loc_net* net);
  * launch per chunk; up to 32 rows (or predict_pieces < 0) use the 32-row kernels. */
 int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets, float* dist,
                 void* stream);
+
+/* Which weight image loc_predict builds and uses for n rows of this net: 0 = none (in-loop conversion or the 32-row
+ * kernels), 1..3 = bf16 pieces (loc_l1_image_build), 12 / 13 = int8 with 2 / 3 digit planes (loc_l1_image_i8_build). */
+int loc_predict_image_mode(const loc_net* net, int n);
 
 /* thin event helpers so a ctypes host can time a kernel on the stream it runs on */
 int loc_event_create(void** ev);

@@ -16,6 +16,14 @@ import torch  # noqa: F401  (side effect: loads torch's libamdhip64 first)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocator_hip.so")
 
+
+def use_library(path):
+    """Measurement tools only (tools/rows_gemm_bench.py --lib): bind another build of the library, e.g. a timing
+    ablation from `make -C locator_amd/csrc ablate A=1`.  Must be called before load()."""
+    global LIB_PATH
+    assert _lib is None, "library already loaded"
+    LIB_PATH = path
+
 c_i32p = C.POINTER(C.c_int32)
 vp = C.c_void_p
 
@@ -40,7 +48,7 @@ class Net(C.Structure):
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
                 ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
                 ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("x_max", C.c_int), ("predict_digits", C.c_int),
-                ("tune", Tuning)]
+                ("l1_image_ready", C.c_int), ("tune", Tuning)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -103,6 +111,7 @@ SIGNATURES = {
                                          C.c_int, vp, vp, C.c_int, vp, vp]),
     "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
+    "loc_predict_image_mode": (C.c_int, [C.POINTER(Net), C.c_int]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),
     "loc_event_destroy": (C.c_int, [vp]),
     "loc_event_record": (C.c_int, [vp, vp]),

@@ -204,6 +204,24 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     return 0;
 }
 
+extern "C" int loc_predict_image_mode(const loc_net* net, int n) {
+    const loc_dims* d = &net->d;
+    const int Hp = d->Hp;
+    const int pieces = net->predict_pieces == 0 ? 3 : net->predict_pieces;
+    const int digits = net->predict_digits == 0 ? 3 : net->predict_digits;
+    if (!(n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) || !net->l1_image)
+        return 0;
+    const int64_t snps_max = (int64_t)d->Kp + 256;          // one SNP group at most: the whole K range
+    if (digits > 0 && net->x_max >= 1 && net->x_max <= 127 && n >= LOC_GEMM_I8_MIN_ROWS(digits) &&
+        loc_l1_gemm_i8_supported(Hp, digits) && net->l1_image_bytes >= loc_l1_image_i8_bytes(d, digits) &&
+        (int64_t)net->x_max * 128 * snps_max < ((int64_t)1 << 31))
+        return 10 + digits;
+    if (n >= LOC_GEMM_MIN_ROWS(pieces) && loc_l1_gemm_supported(Hp, pieces) &&
+        net->l1_image_bytes >= loc_l1_image_bytes(d, pieces))
+        return pieces;
+    return 0;
+}
+
 extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets,
                            float* dist, void* stream) {
     if (n <= 0) return 0;
@@ -220,17 +238,15 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     const int digits = net->predict_digits == 0 ? 3 : net->predict_digits;
     if (n > LOC_ROWS && pieces > 0 && loc_stack_fused_supported(Hp) && loc_l1_rows_supported(Hp, pieces)) {
         // large-M layer 1 on the matrix pipe, then ONE row-parallel stack launch per chunk.  Many rows: the weights are
-        // converted once into the caller's image buffer and every chunk runs a pure-MFMA GEMM - on the int8 pipe when
-        // the genotypes are known to fit (x_max <= 127) and no SNP group can overflow int32, else on bf16 pieces
-        const int64_t snps_max = (int64_t)d->Kp + 256;      // one SNP group at most: the whole K range
-        const bool i8 = digits > 0 && net->x_max >= 1 && net->x_max <= 127 && n >= LOC_GEMM_I8_MIN_ROWS(digits) &&
-                        net->l1_image && loc_l1_gemm_i8_supported(Hp, digits) &&
-                        net->l1_image_bytes >= loc_l1_image_i8_bytes(d, digits) &&
-                        (int64_t)net->x_max * 128 * snps_max < ((int64_t)1 << 31);
-        const bool gemm = !i8 && n >= LOC_GEMM_MIN_ROWS(pieces) && net->l1_image && loc_l1_gemm_supported(Hp, pieces) &&
-                          net->l1_image_bytes >= loc_l1_image_bytes(d, pieces);
-        if (i8) TRY(loc_l1_image_i8_build(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
-        if (gemm) TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
+        // converted once into the caller's image buffer (or found there: l1_image_ready) and every chunk runs a pure-MFMA
+        // GEMM - on the int8 pipe when the genotypes are known to fit (x_max <= 127) and no SNP group can overflow
+        // int32, else on bf16 pieces
+        const int mode = loc_predict_image_mode(net, n);
+        const bool i8 = mode >= 12, gemm = mode >= 1 && mode <= 3;
+        if (mode && net->l1_image_ready != mode) {
+            if (i8) TRY(loc_l1_image_i8_build(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
+            else TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
+        }
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
             if (i8)

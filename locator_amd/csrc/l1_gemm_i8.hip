@@ -52,21 +52,27 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------
 // per-unit scale and digit image
 // ---------------------------------------------------------------------------------------------------------
-// One workgroup per 64-SNP block, thread = unit n (the addressing of l1_image_kernel).  colmax[n] = max |s_k W1[k][n]|
-// as the bit pattern of a non-negative float: atomicMax on it is order-independent, so the result is deterministic.
+// Thread = unit n (the addressing of l1_image_kernel), workgroup b walks the 64-SNP blocks b, b + grid, ...: one atomicMax
+// per unit and workgroup at the end (a few hundred workgroups, not one per block: the atomics all hit the same 256
+// words).  colmax[n] = max |s_k W1[k][n]| as the bit pattern of a non-negative float: the maximum is order-independent,
+// so the result is deterministic.
 __global__ __launch_bounds__(G8_HP) void l1_colmax_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
-                                                          int Kp, uint32_t* __restrict__ colmax) {
+                                                          int Kp, int nkt64, uint32_t* __restrict__ colmax) {
     constexpr int nht = G8_HP / 32;
-    const int kt64 = blockIdx.x, n = threadIdx.x;
+    const int n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
     float mx = 0.f;
+    for (int kt64 = blockIdx.x; kt64 < nkt64; kt64 += gridDim.x) {
 #pragma unroll
-    for (int h32 = 0; h32 < 2; ++h32) {
-        const int kt32 = 2 * kt64 + h32;
-        if (kt32 * 32 < Kp) {
-            const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128 + c4;
+        for (int h32 = 0; h32 < 2; ++h32) {
+            const int kt32 = 2 * kt64 + h32;
+            if (kt32 * 32 < Kp) {
+                const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128 + c4;
+                float m4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kl = 0; kl < 32; ++kl) mx = fmaxf(mx, fabsf(src[kl * 4] * ss4[kt32 * 32 + kl]));
+                for (int kl = 0; kl < 32; ++kl) m4[kl & 3] = fmaxf(m4[kl & 3], fabsf(src[kl * 4] * ss4[kt32 * 32 + kl]));
+                mx = fmaxf(mx, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+            }
         }
     }
     if (mx > 0.f) atomicMax(colmax + n, fbits(mx));
@@ -146,19 +152,21 @@ __device__ __forceinline__ uint32_t lds_addr32_i8(const void* p) {
 // the four A fragments (row tiles 0..3) of one 32-SNP step by four 16-byte LDS reads; volatile so that they stay in
 // the load phase, ahead of the barrier that hands the matrix pipe to this wave
 __device__ __forceinline__ void rd4_i8(i32x4& a0, i32x4& a1, i32x4& a2, i32x4& a3, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\t"
-                 "ds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536"
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+                 "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
                  : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(addr) : "memory");
 }
 // Global loads as asm with hand-counted s_waitcnt vmcnt (see l1_gemm.hip: the compiler's own counts collapse at the
-// loop header).  COUNT TABLE, per wave, requests in program order:
-//   load phase of a block     1 genotype request (16 bytes per lane)
-//   matrix phase of a block   D digit tiles x 2 fragment requests, each issued right after the 4 MFMAs that consumed
-//                             the fragment it replaces, G8_RING tiles ahead
-//   => a fragment about to be consumed was requested G8_RING tiles ago; younger than it are 2*G8_RING - 1 fragment
-//      requests and the G8_RING / D genotype requests of the blocks crossed:      vmcnt(2*G8_RING - 1 + G8_RING/D)
-//   => the genotype bytes stored in a load phase were requested two blocks ago; younger than them are the 2*2*D fragment
-//      requests of two matrix phases and one genotype request:                    vmcnt(4*D + 1)
+// loop header).  COUNT TABLE, per wave, requests in program order.  One iteration = one PAIR of 64-SNP blocks =
+// 4 steps of 32 SNPs; FP = 4 D digit fragments per pair, consumed in the order (step, plane); NB = G8_NB fragments
+// in flight:
+//   head of an iteration   2 genotype requests (16 bytes per lane each: this thread's share of the pair after next)
+//   after each 4 MFMAs     1 fragment request, NB fragments ahead of the one just consumed
+//   => fragment j of a pair (j = 0..FP-1) was requested NB fragments ago; younger than it are NB - 1 fragment requests
+//      and 2 genotype requests per iteration head crossed (g8_heads() below):     vmcnt(NB - 1 + 2 heads)
+//      (a LOC_GEMM_DEBUG_DRAIN build replaces every count by vmcnt(0) for parity debugging)
+//   => the genotype bytes stored at the head of an iteration were requested at the previous head; younger than them
+//      are that iteration's FP fragment requests:                                  vmcnt(FP)
 template <typename T>
 __device__ __forceinline__ void gload16_i8(T& r, const void* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
@@ -172,123 +180,191 @@ __device__ __forceinline__ void wait_vm_i8() {
 #endif
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ void phase_barrier_i8() {
+__device__ __forceinline__ void wait_lgkm0_i8() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void barrier_i8() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// iteration heads (2 genotype requests each) between the request of fragment j of a pair and its consumption NB
+// fragments later: a fragment F = c FP + j is requested right after F - NB is consumed and the head of iteration c'
+// sits just before fragment c' FP, so the heads counted are those with F - NB < c' FP <= F:  ceil((NB - j) / FP)
+constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1) / FP : 0; }
+
+// Timing ablations (never in the product build: `make ablate A=<bits>` writes ../liblocator_hip_ablate<bits>.so, results
+// are wrong by construction): 1 no fragment requests in the loop, 2 no genotype requests / stores, 4 no rendezvous,
+// 8 no A-fragment reads, 16 genotype DMA always from the group's first pair (L2-hot), 32 in-kernel stamps: every wave
+// adds up the shader cycles it spends in the fragment waits, the DMA wait, the rendezvous and the LDS waits and
+// leaves them (with its total) where its partial sums would go (tools/rows_gemm_bench.py --stamps).
+#ifndef LOC_GEMM_ABLATE
+#define LOC_GEMM_ABLATE 0
+#endif
+
+#ifndef G8_NB
+#define G8_NB 12      /* digit fragments in flight per wave (48 registers): 1.5 pairs at two planes, 3 at one      */
+#endif
+#define G8_RP 8       /* pairs in the genotype ring (8 x 16 KB)                                                    */
+
+#ifndef G8_LA
+#define G8_LA 4       /* pairs between a genotype DMA and the iteration that reads it                               */
+#endif
+#ifndef G8_DMA_MOD
+#define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1", ...)                              */
+#endif
+
+#if LOC_GEMM_ABLATE & 32
+#define G8_T0() const uint64_t t0__ = __builtin_amdgcn_s_memtime()
+#define G8_T1(slot) c.prof[slot] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0__)
+#else
+#define G8_T0()
+#define G8_T1(slot)
+#endif
 
 struct g8_ctx {
-    const uint8_t* xsrc[2];
+    mutable uint32_t prof[6];     // stamps build: cycles in [fragment waits, DMA wait, rendezvous, LDS waits]
+    const uint8_t* xrow[2];       // this lane's two genotype rows (DMA role): rows 16 w + 8 i + (lane >> 3)
+    uint32_t xpiece[2];           // 16 x the piece of the pair's 128-byte line this lane fetches for each of them
     const unsigned char* tiles;
     unsigned char* As;
-    int g, G, cntp, Kp, q, xr, w, jl, hi;
+    int p0, cntp, Kp, w, jl, hi, lane;   // this group's pairs of 64-SNP blocks: [p0, p0 + cntp)
 };
 
+// 16 bytes per lane global -> LDS without passing a register (LDS-DMA): the wave's 64 lanes fill the 1 KB at `lds_dst`
+// (wave-uniform) in lane order, each from its own address.  M0 is the destination base and is compiler-reserved: saved,
+// set and restored inside the one statement (guide: cdna_hip_programming.md, "LDS-DMA recipe").
+__device__ __forceinline__ void dma16_i8(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" G8_DMA_MOD "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // One walk over this workgroup's SNP blocks with D digit planes [plane0, plane0 + D) of the DT planes in the image.
+// All eight waves run the same software-pipelined stream and meet once per pair.  Genotypes: at the head of an
+// iteration the wave starts the DMA of its 16 rows of the pair G8_LA iterations ahead (two requests of 8 rows x 128
+// bytes; ring of G8_RP pairs x 16 KB, row m at m*128 with its eight 16-byte pieces XOR-placed by (m >> 1) & 7, which
+// keeps both the lane-linear DMA stores and the 16-lane read groups on distinct banks) - no register, no LDS store
+// instruction, and four pairs of slack against HBM latency.  Each 32-SNP step then waits for the A fragments it
+// prefetched one step earlier, prefetches the next step's four fragments (16 registers, double buffered) and issues
+// D x 4 MFMAs, one fragment request after every 4 (saddr form: the pair base is a scalar, the lane part and the
+// in-pair constant sit in FP VGPRs - no address arithmetic in the loop).  The rendezvous sits in the middle of the
+// pair - before it the wave waits for its own share of the NEXT pair's DMA - so the first step of the next pair is
+// prefetched half a pair ahead of its use and nobody waits for an LDS round trip after it; the two waves of a SIMD
+// are NOT phase-locked: whichever has operands feeds the matrix pipe.
 template <int D, int DT>
 __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&acc)[D][4]) {
-    static_assert(G8_RING % D == 0 && (6 * D) % G8_RING == 0, "ring / unroll shapes");
-    const int cnt = 2 * c.cntp, nT = cnt * D;
-    auto load_x = [&](u32x4& R, int pc, int i) {
-        const int cc = pc < c.cntp ? pc : c.cntp - 1;
-        int koff = (c.g + cc * c.G) * (2 * G8_BK) + 16 * c.q;
-        if (koff > c.Kp - 16) koff = c.Kp - 16;            // only in the zero-weight padding of the last pair
-        gload16_i8(R, c.xsrc[i] + koff);
+    constexpr int FP = 4 * D;                               // fragments per pair
+    // pairs per unrolled body, so that the ring slot of every fragment is static: the smallest UP with UP FP % NB == 0
+    constexpr int UP = (FP % G8_NB == 0) ? 1 : ((2 * FP) % G8_NB == 0) ? 2 : ((3 * FP) % G8_NB == 0) ? 3 : 4;
+    static_assert((UP * FP) % G8_NB == 0 && G8_RP >= G8_LA + 2, "ring / unroll shapes");
+    const uint32_t lds0 = lds_addr32_i8(c.As);
+    auto dma_x = [&](int pc, int i) {
+        int cc = pc < c.cntp ? pc : c.cntp - 1;
+        if (LOC_GEMM_ABLATE & 16) cc = 0;
+        uint32_t koff = (uint32_t)(c.p0 + cc) * (2 * G8_BK) + c.xpiece[i];
+        if (koff > (uint32_t)(c.Kp - 16)) koff = c.Kp - 16; // only in the zero-weight padding of the last pair
+        dma16_i8(c.xrow[i] + koff, lds0 + (pc % G8_RP) * (2 * G8_AIMG) + (16 * c.w + 8 * i) * 128);
     };
-    // 16 bytes = chunk c4 = q & 3 of block e = q >> 2 of the pair, row xr + 64 i: slot (2 pc + e) & 3, at
-    // c4*2048 + ((row ^ q) << 4).  The 8 lanes of a store group (one row, q = 0..7) land on 8 different 16-byte
-    // bank groups, and so do the 16 lanes of a read group (one chunk, 16 rows that differ in their low 4 bits).
-    const uint32_t woff = (c.q >> 2) * G8_AIMG + (c.q & 3) * 2048;
-    auto stage = [&](const u32x4& R, int pc, int i) {
-        const int row = c.xr + 64 * i;
-        unsigned char* ad = c.As + woff + ((2 * pc) & 3) * G8_AIMG + ((row ^ c.q) << 4);
-        *reinterpret_cast<u32x4*>(ad) = R;
-    };
-    const int b_lane = c.hi * 4096 + (c.w * 32 + c.jl) * 16;
-    auto load_b = [&](i32x4& R, int j, int kk) {           // fragment kk of digit tile j = block * D + p
-        const int jj = j < nT ? j : nT - 1;
-        const int a = jj / D, p = jj - a * D;
-        const int kt = 2 * (c.g + (a >> 1) * c.G) + (a & 1);
-        gload16_i8(R, c.tiles + ((int64_t)kt * DT + plane0 + p) * G8_TILE + b_lane + kk * 8192);
-    };
-    uint32_t aoff[2][2];                                    // A-fragment addresses for even / odd blocks
+    // Fragment j = step * D + p of a pair sits at  pair base + voff[j],  voff[j] = lane part + e DT TILE + kk 8192 + p TILE
+    // (step = 2 e + kk)
+    uint32_t voff[FP];
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            aoff[e][kk] = lds_addr32_i8(c.As) + (2 * kk + c.hi) * 2048 + ((c.jl ^ (4 * e + 2 * kk + c.hi)) << 4);
-
-    // prologue: pair 0 stored at once, pair 1 and digit tiles 0..RING-1 requested
-    u32x4 XR[2];
-    i32x4 B[G8_RING][2];
-    {
-        u32x4 x0, x1;
-        load_x(x0, 0, 0);
-        load_x(x1, 0, 1);
-        load_x(XR[0], 1, 0);
-        load_x(XR[1], 1, 1);
-#pragma unroll
-        for (int j = 0; j < G8_RING; ++j) { load_b(B[j][0], j, 0); load_b(B[j][1], j, 1); }
-        wait_vm_i8<0>();
-        stage(x0, 0, 0);
-        stage(x1, 0, 1);
+    for (int j = 0; j < FP; ++j) {
+        const int st = j / D, p = j - st * D;
+        voff[j] = (uint32_t)(c.hi * 4096 + (c.w * 32 + c.jl) * 16 + (st >> 1) * (DT * G8_TILE) + (st & 1) * 8192 +
+                             (plane0 + p) * G8_TILE);
     }
-    __syncthreads();
+    auto pair_base = [&](int pc) -> const unsigned char* { // pairs past the end re-read the last one (never used)
+        const int cc = pc < c.cntp ? pc : c.cntp - 1;
+        return c.tiles + (int64_t)(c.p0 + cc) * (2 * DT * G8_TILE);
+    };
+    auto load_b = [&](i32x4& R, const unsigned char* sbase, uint32_t vo) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(R) : "v"(vo), "s"(sbase) : "memory");
+    };
+    uint32_t aoff[4];                                       // A fragment of step st = 2 e + kk: piece 4 e + 2 kk + hi of row jl
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+        aoff[st] = lds0 + c.jl * 128 + (((2 * st + c.hi) ^ ((c.jl >> 1) & 7)) << 4);
 
-    const int grp = c.w >> 2;
-    if (grp == 1) phase_barrier_i8();
-    auto block = [&](int bb, auto alc) {
-        constexpr int al = decltype(alc)::value;
-        const int ai = bb + al;
-        const uint32_t so = (ai & 3) * G8_AIMG;
-        i32x4 a[2][4];
+    // prologue: pairs 0..LA-1 and fragments 0..NB-1 requested, step 0 of pair 0 fetched
+    i32x4 B[G8_NB];
+    i32x4 A[2][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) rd4_i8(a[kk][0], a[kk][1], a[kk][2], a[kk][3], aoff[al & 1][kk] + so);
-        wait_vm_i8<4 * D + 1>();
-        stage(XR[al & 1], (ai >> 1) + 1, al & 1);
-        load_x(XR[al & 1], (ai >> 1) + 2, al & 1);
-        phase_barrier_i8();
+    for (int pc = 0; pc < G8_LA; ++pc) { dma_x(pc, 0); dma_x(pc, 1); }
 #pragma unroll
-        for (int p = 0; p < D; ++p) {
-            const int u = al * D + p;                       // static after unrolling
+    for (int f = 0; f < G8_NB; ++f) load_b(B[f], pair_base(f / FP), voff[f % FP]);
+    wait_vm_i8<0>();
+    barrier_i8();
+    rd4_i8(A[0][0], A[0][1], A[0][2], A[0][3], aoff[0]);
+
+    // vmcnt before the rendezvous of iteration pc: this wave's DMA of pair pc + 1 was issued LA - 1 heads ago; younger are
+    // the (LA - 1) later heads' 2 requests each, (LA - 1) whole iterations of FP fragment requests and the 2 D of steps 0, 1
+    constexpr int N_DMA = 2 * (G8_LA - 1) + (G8_LA - 1) * FP + 2 * D;
+    auto pair = [&](int pc0, auto uc) {
+        constexpr int u = decltype(uc)::value;             // position inside the unrolled body: ring slots are static
+        const int pc = pc0 + u;
+        if (!(LOC_GEMM_ABLATE & 2)) {
+            dma_x(pc + G8_LA, 0);
+            dma_x(pc + G8_LA, 1);
+        }
+        const uint32_t so = (pc % G8_RP) * (2 * G8_AIMG), so1 = ((pc + 1) % G8_RP) * (2 * G8_AIMG);
+        // the pairs the fragments requested in this iteration belong to: NB fragments ahead
+        const unsigned char* const sb_lo = pair_base(pc + G8_NB / FP);
+        const unsigned char* const sb_hi = pair_base(pc + G8_NB / FP + 1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                wait_vm_i8<2 * G8_RING - 1 + G8_RING / D>();
+        for (int st = 0; st < 4; ++st) {
+            if (st == 2 && !(LOC_GEMM_ABLATE & 4)) {
+                { G8_T0(); wait_vm_i8<N_DMA>(); G8_T1(1); } // my rows of pair pc + 1 are in the ring
+                { G8_T0(); barrier_i8(); G8_T1(2); }        // ... and so are everyone's; nobody still reads pair pc - 1
+            } else {
+                G8_T0(); wait_lgkm0_i8(); G8_T1(3);         // A[st & 1] has landed
+            }
+            if (LOC_GEMM_ABLATE & 8) {}
+            else if (st < 3) rd4_i8(A[(st + 1) & 1][0], A[(st + 1) & 1][1], A[(st + 1) & 1][2], A[(st + 1) & 1][3], aoff[st + 1] + so);
+            else rd4_i8(A[0][0], A[0][1], A[0][2], A[0][3], aoff[0] + so1);
+#pragma unroll
+            for (int p = 0; p < D; ++p) {
+                const int j = st * D + p;                   // fragment of the pair; static after unrolling
+                const int slot = (u * FP + j) % G8_NB;
+                G8_T0();
+                if (g8_heads(j, FP, G8_NB) == 1) wait_vm_i8<G8_NB - 1 + 2>();
+                else if (g8_heads(j, FP, G8_NB) == 2) wait_vm_i8<G8_NB - 1 + 4>();
+                else if (g8_heads(j, FP, G8_NB) == 3) wait_vm_i8<G8_NB - 1 + 6>();
+                else if (g8_heads(j, FP, G8_NB) == 4) wait_vm_i8<G8_NB - 1 + 8>();
+                else if (g8_heads(j, FP, G8_NB) == 5) wait_vm_i8<G8_NB - 1 + 10>();
+                else wait_vm_i8<G8_NB - 1>();
+                G8_T1(0);
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
-                    acc[p][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk][tm], B[u % G8_RING][kk], acc[p][tm], 0, 0, 0);
+                    acc[p][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[st & 1][tm], B[slot], acc[p][tm], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_b(B[u % G8_RING][kk], bb * D + u + G8_RING, kk);
+                if (!(LOC_GEMM_ABLATE & 1)) load_b(B[slot], (j + G8_NB % FP) < FP ? sb_lo : sb_hi, voff[(j + G8_NB) % FP]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        phase_barrier_i8();
     };
-    // whole bodies of 6 blocks (ring slot and block parity static), then the even remainder
-    int bb = 0;
-    for (; bb + 6 <= cnt; bb += 6) {
-        block(bb, std::integral_constant<int, 0>{});
-        block(bb, std::integral_constant<int, 1>{});
-        block(bb, std::integral_constant<int, 2>{});
-        block(bb, std::integral_constant<int, 3>{});
-        block(bb, std::integral_constant<int, 4>{});
-        block(bb, std::integral_constant<int, 5>{});
+    int pc = 0;
+    for (; pc + UP <= c.cntp; pc += UP) {
+        pair(pc, std::integral_constant<int, 0>{});
+        if (UP > 1) pair(pc, std::integral_constant<int, 1>{});
+        if (UP > 2) pair(pc, std::integral_constant<int, 2>{});
+        if (UP > 3) pair(pc, std::integral_constant<int, 3>{});
     }
-    if (bb < cnt) {                                         // cnt is even: 2 or 4 blocks left
-        block(bb, std::integral_constant<int, 0>{});
-        block(bb, std::integral_constant<int, 1>{});
-        if (bb + 2 < cnt) {
-            block(bb, std::integral_constant<int, 2>{});
-            block(bb, std::integral_constant<int, 3>{});
-        }
+    if (UP > 1 && pc < c.cntp) {                            // up to UP - 1 pairs left; the ring is back at slot 0
+        pair(pc, std::integral_constant<int, 0>{});
+        if (UP > 2 && pc + 1 < c.cntp) pair(pc, std::integral_constant<int, 1>{});
+        if (UP > 3 && pc + 2 < c.cntp) pair(pc, std::integral_constant<int, 2>{});
     }
     // requests past the end (clamped, never used) are still landing: drain them while their registers are allocated
     wait_vm_i8<0>();
+    wait_lgkm0_i8();
 #pragma unroll
-    for (int j = 0; j < G8_RING; ++j) asm volatile("" ::"v"(B[j][0]), "v"(B[j][1]));
-    asm volatile("" ::"v"(XR[0]), "v"(XR[1]));
-    if (grp == 0) phase_barrier_i8();
+    for (int f = 0; f < G8_NB; ++f) asm volatile("" ::"v"(B[f]));
+    asm volatile("" ::"v"(A[0][0]), "v"(A[0][1]), "v"(A[0][2]), "v"(A[0][3]));
+    __syncthreads();                                        // the epilogue's staging images overlap the ring
 }
 
 template <int DT>
@@ -300,30 +376,39 @@ __global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __rest
     extern __shared__ __attribute__((aligned(1024))) unsigned char g8_smem[];
     const int t = threadIdx.x, lane = t & 63;
     g8_ctx c;
+#if LOC_GEMM_ABLATE & 32
+    for (int i = 0; i < 6; ++i) c.prof[i] = 0;
+    const uint64_t t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
+#endif
     c.w = __builtin_amdgcn_readfirstlane(t >> 6);
+    c.lane = lane;
     c.jl = lane & 31;
     c.hi = lane >> 5;
-    int mt;
+    int mt, g;
     if ((G & 7) == 0) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         mt = idx % n_mt;
-        c.g = xcd + 8 * (idx / n_mt);
+        g = xcd + 8 * (idx / n_mt);
     } else {
-        c.g = blockIdx.x % G;
+        g = blockIdx.x % G;
         mt = blockIdx.x / G;
     }
-    c.G = G;
+    // group g owns a CONTIGUOUS run of pairs (balanced to within one): a workgroup then walks each of its 128 genotype
+    // rows sequentially, which HBM serves at 6.0 TB/s where the interleaved assignment of l1_gemm.hip (every G-th pair)
+    // tops out at 4.2 (tools/probes/geno_stream_probe.hip, profiles/r03_geno_stream_probe.jsonl)
+    const int qp = npairs / G, rp = npairs - qp * G;
+    c.p0 = g * qp + (g < rp ? g : rp);
+    c.cntp = qp + (g < rp ? 1 : 0);
     c.Kp = Kp;
     c.tiles = tiles;
     c.As = g8_smem;
-    c.cntp = (npairs - c.g + G - 1) / G;
-    c.xr = t >> 3;
-    c.q = t & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int r = mt * G8_BM + c.xr + 64 * i;
+        const int m = 16 * c.w + 8 * i + (lane >> 3);      // row of the 128-row tile this lane moves
+        int r = mt * G8_BM + m;
         if (r > n - 1) r = n - 1;
-        c.xsrc[i] = X + (int64_t)rows[r] * pitch;
+        c.xrow[i] = X + (int64_t)rows[r] * pitch;
+        c.xpiece[i] = (uint32_t)(((lane & 7) ^ ((m >> 1) & 7)) << 4);
     }
     const int Mp = n_mt * G8_BM;
 
@@ -341,7 +426,7 @@ __global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __rest
     // set costs at 256 registers per wave.
     const float dl = delta[c.w * 32 + c.jl];
     float* const ep = reinterpret_cast<float*>(g8_smem) + c.w * 4096;
-    float* const pout = partial + ((int64_t)c.g * Mp + mt * G8_BM) * G8_HP + c.w * 32;
+    float* const pout = partial + ((int64_t)g * Mp + mt * G8_BM) * G8_HP + c.w * 32;
     auto emit = [&](const i32x16 (&hi_p)[4], const i32x16 (&lo_p)[4], float s_hi, float s_lo, bool add) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
@@ -358,6 +443,21 @@ __global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __rest
             *dst = v;
         }
     };
+#if LOC_GEMM_ABLATE & 32
+    {
+        const uint64_t t_loop = __builtin_amdgcn_s_memtime();
+        emit(acc[0], acc[1], 256.f, 1.f, false);
+        __syncthreads();
+        const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            float* o = partial + ((int64_t)blockIdx.x * 8 + c.w) * 16;
+            o[0] = (float)(t_end - t_start); o[1] = (float)(t_loop - t_start); o[2] = (float)(r_end - r_start);
+            for (int i = 0; i < 4; ++i) o[3 + i] = (float)c.prof[i];
+            o[7] = 12345.f;
+        }
+        return;
+    }
+#endif
     if (DT == 2) {
         emit(acc[0], acc[1], 256.f, 1.f, false);
     } else {
@@ -407,7 +507,7 @@ extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
     if (e != hipSuccess) { loc_set_error("loc_l1_image_i8_build: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(l1_colmax_kernel, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax);
+    hipLaunchKernelGGL(l1_colmax_kernel, dim3(nkt < 512 ? nkt : 512), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax);
     LOC_CHECK_LAUNCH();
     if (digits == 2)
         hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax, delta, tiles, cpart);

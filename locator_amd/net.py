@@ -93,10 +93,15 @@ class LocatorNet:
         self.predict_pieces = int(predict_pieces)
         self.predict_digits = int(predict_digits)
         self.tuning = _lib.Tuning(**{k: int(v) for k, v in (tuning or {}).items()})
-        self.l1_image = None               # bf16 image of s_k*W1 for many-row predicts (allocated on first use)
+        self.l1_image = None               # image of s_k*W1 for many-row predicts (allocated on first use)
+        self._image_mode = 0               # loc_predict_image_mode() of the image l1_image holds for the current parameters
         self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
         self._net = None
         self.init_weights()
+
+    def params_changed(self):
+        """Weights, gamma/beta or BatchNorm moving statistics are about to change: a kept many-row weight image is stale."""
+        self._image_mode = 0
 
     def set_batch(self, batch_size):
         """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..128 rows run two to
@@ -145,6 +150,7 @@ class LocatorNet:
         (SURVEY.md A.1).  Streams are keyed by (seed, replicate, layer) so a replicate's init does not
         depend on which GPU or in which order it runs."""
         d, lay, lib = self.d, self.lay, self.lib
+        self.params_changed()
         self.params.zero_()
         self.adam_m.zero_()
         self.adam_v.zero_()
@@ -243,6 +249,7 @@ class LocatorNet:
 
     def import_params(self, p):
         self.check_params(p)
+        self.params_changed()
         self._import_flat(self.params, p)
         self.refresh_transposed()
 
@@ -251,6 +258,7 @@ class LocatorNet:
         """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
         mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view.
         bn_ready / bn_next: epoch-level BN statistics (see epoch_bn_stats)."""
+        self.params_changed()
         net = self._net or self.cnet()
         _lib.check(self.lib.loc_train_step(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
                                            _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next), ev0, ev1, _stream()),
@@ -259,6 +267,7 @@ class LocatorNet:
     def epoch_bn_stats(self, rows_all, batch, n_last, n_steps, stats_ep):
         """BN batch statistics of every minibatch of the epoch in one launch, the epoch's moving-statistics
         updates, and step 0's scale/shift (loc_bn_epoch_stats)."""
+        self.params_changed()
         net = self._net or self.cnet()
         d, lay, P = self.d, self.lay, self.params.data_ptr()
         _lib.check(self.lib.loc_bn_epoch_stats(self.X.data_ptr(), self.X.stride(0), _ptr(rows_all), int(batch),
@@ -285,8 +294,14 @@ class LocatorNet:
             self.l1_image = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._net = None
         net = self._net or self.cnet()
+        # predict_locs predicts twice with the same weights (locator.py:414, :441): the second call finds the image
+        mode = lib.loc_predict_image_mode(C.byref(net), int(n))
+        net.l1_image_ready = mode if (mode and mode == self._image_mode
+                                      and not torch.cuda.is_current_stream_capturing()) else 0
         _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
                                         _ptr(dist), _stream()), "loc_predict")
+        if mode:
+            self._image_mode = mode
 
     def genotype_max(self):
         """Largest genotype value of the current X (one streaming pass, cached per matrix): decides whether the rows
@@ -313,6 +328,7 @@ class LocatorNet:
     def restore_best(self):
         """model.load_weights(best) (locator.py:379-388)."""
         if self.best is not None:
+            self.params_changed()
             self.params.copy_(self.best)
             self.refresh_transposed()
 

@@ -111,6 +111,7 @@ class EpochRunner:
         be in flight at once, replicates.py / bench.py --replicates-per-gpu).  perm: permutation of range(n_train)
         (Keras shuffle=True draws it unseeded; here it is an input)."""
         net = self.net
+        net.params_changed()                 # a graph replay trains without passing through net.train_step
         rows = self.train_rows[np.asarray(perm)]
         self.perm_host[:self.n_train] = torch.from_numpy(rows)
         self.perm_host[self.n_train:] = 0

@@ -234,3 +234,32 @@ def test_predict_takes_the_int8_path_only_when_the_genotypes_allow_it():
     torch.cuda.synchronize()
     assert net.genotype_max() == 200 and net.l1_image.numel() == net.lib.loc_l1_image_bytes(C.byref(net.d), 3)
     assert maxerr(yhat.cpu().numpy(), O.predict(p, x2)) < 2e-5
+
+
+def test_second_predict_with_unchanged_weights_reuses_the_image_and_any_change_rebuilds_it():
+    """predict_locs predicts twice with the same weights (locator.py:414, :441): the second many-row call must skip the
+    conversion (loc_net.l1_image_ready) and give identical numbers; a training step in between must rebuild it."""
+    from oracle import locator_oracle as O
+    K, width, n = 2000, 256, 700
+    x, y, p, rng = make_problem(n, K, width, 4, seed=33)
+    net = build_net(x, y, p)
+    rows = torch.arange(n, dtype=torch.int32, device="cuda")
+    y1, y2, y3 = (torch.zeros((n, 2), device="cuda") for _ in range(3))
+    net.predict_rows(rows, n, y1)
+    assert net._image_mode == 13 and net._net.l1_image_ready == 0
+    sl = slice(50_000, 54_096)                        # inside the first digit tiles (they start at byte 43,008)
+    assert net.l1_image[sl].any()
+    net.l1_image[sl].zero_()                          # if the second call rebuilt the image these bytes would come back
+    tail = net.l1_image[sl].clone()
+    net.predict_rows(rows, n, y2)
+    torch.cuda.synchronize()
+    assert net._net.l1_image_ready == 13 and torch.equal(net.l1_image[sl], tail)
+    net.import_params(O.cast_params(p, np.float32))   # same values, but "changed": rebuild restores the zeroed tail
+    net.predict_rows(rows, n, y3)
+    torch.cuda.synchronize()
+    assert net._net.l1_image_ready == 0 and not torch.equal(net.l1_image[sl], tail)
+    assert torch.equal(y1, y3) and maxerr(y1.cpu().numpy(), O.predict(p, x)) < 2e-5
+    loss = torch.zeros(1, device="cuda")
+    mask = torch.ones(32 * width, dtype=torch.uint8, device="cuda")
+    net.train_step(rows, 32, 1, mask, loss)
+    assert net._image_mode == 0

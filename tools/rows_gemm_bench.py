@@ -31,7 +31,12 @@ def main():
     ap.add_argument("--blocks", default="0")
     ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMMs (l1_gemm.hip, l1_gemm_i8.hip)")
     ap.add_argument("--i8-only", action="store_true", help="only the int8 GEMM (l1_gemm_i8.hip)")
+    ap.add_argument("--lib", default=None, help="another build of liblocator_hip.so (timing ablations)")
+    ap.add_argument("--stamps", action="store_true",
+                    help="with a stamps build (make ablate A=32): decode the per-wave cycle counts left in the scratch")
     a = ap.parse_args()
+    if a.lib:
+        _lib.use_library(os.path.abspath(a.lib))
     dev = torch.device("cuda:0")
     n_max = max(int(r) for r in a.rows.split(","))
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -107,6 +112,17 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
+                if a.stamps:
+                    st = partial[:256 * 8 * 16].view(256 * 8, 16).cpu().numpy()
+                    st = st[st[:, 7] == 12345.0]
+                    tot = st[:, 0].mean()
+                    print(json.dumps({"stamps": "mean over %d waves" % len(st), "digits": digits, "cycles_total": round(float(tot)),
+                                      "cycles_loop": round(float(st[:, 1].mean())), "clock_ghz": round(float((st[:, 0] / st[:, 2]).mean()) * 0.1, 3),
+                                      "frac_fragment_waits": round(float((st[:, 3] / st[:, 0]).mean()), 3),
+                                      "frac_dma_wait": round(float((st[:, 4] / st[:, 0]).mean()), 3),
+                                      "frac_rendezvous": round(float((st[:, 5] / st[:, 0]).mean()), 3),
+                                      "frac_lds_waits": round(float((st[:, 6] / st[:, 0]).mean()), 3),
+                                      "max_wave_cycles": round(float(st[:, 0].max())), "min_wave_cycles": round(float(st[:, 0].min()))}))
                 flops = 2.0 * n * a.snps * a.width
                 rec = {"kernel": "int8 image+gemm", "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
                        "digits": digits, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
