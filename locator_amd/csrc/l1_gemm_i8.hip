@@ -207,10 +207,10 @@ constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1
 #ifndef G8_NB
 #define G8_NB 12      /* digit fragments in flight per wave (48 registers): 1.5 pairs at two planes, 3 at one      */
 #endif
-#define G8_RP 8       /* pairs in the genotype ring (8 x 16 KB)                                                    */
+#define G8_RP 4       /* pairs in the genotype ring (4 x 16 KB) >= G8_LA + 2                                       */
 
 #ifndef G8_LA
-#define G8_LA 4       /* pairs between a genotype DMA and the iteration that reads it                               */
+#define G8_LA 2       /* pairs between a genotype DMA and the iteration that reads it (measured: 2 beats 1, 3, 4)  */
 #endif
 #ifndef G8_DMA_MOD
 #define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1", ...)                              */
