@@ -29,8 +29,11 @@ The JSON line also carries
   cpu_baseline  the torch-CPU fp32 restatement of the same epochs (oracle/torch_cpu.py: "restated reference on CPU
                 (torch), not TensorFlow") on this box's physical cores, validation sweep included,
                 bounded to ~12 s; `numpy_port` = the single-threaded-Adam NumPy oracle step for comparison.
-  l1_gemm       (N=1) the large-M first-layer genotype GEMM (model.predict over all 1000 rows) as a fraction of the
-                dense bf16-MFMA peak: image + GEMM path (l1_gemm.hip) and the in-loop-conversion kernel.
+  l1_gemm       (N=1) the large-M first-layer genotype GEMM (model.predict over all 1000 rows; 4096 rows of the same
+                matrix = the batched --jacknife; 4096 DISTINCT rows streaming from HBM) as a fraction of the dense
+                bf16-MFMA peak, for every predict mode the CLI ships - int8 x 3 digits (default, exact), int8 x 2
+                (fast), bf16 x 3 / 2 / 1 pieces - each with the tolerance its predictions are tested to, plus the
+                in-loop-conversion kernel used for few rows.
 """
 import argparse
 import hashlib
@@ -135,15 +138,29 @@ def _time_burst(fn, n=3, idle_s=0.25):
     return best
 
 
-def l1_gemm_roofline(net, n_matrix, iters=20):
+# Predict modes the CLI ships (locator_amd/locator.py --predict_mode / --predict_pieces) and the bar each one is held to
+# on the PREDICTIONS at this workload's K (tests/test_gpu_baseline_sizes.py::test_config2_predict_all_rows):
+PREDICT_MODE_INFO = {
+    "int8x3": "default (--predict_mode exact): 24-bit fixed point per weight, predictions 2e-5 absolute / <= 1e-3 relative",
+    "int8x2": "--predict_mode fast: 16-bit fixed point per weight, predictions <= 1e-3 relative (north_star bound)",
+    "bf16x3": "--predict_pieces 3 (and the fallback for genotypes > 127): fp32-exact products, 2e-5 absolute",
+    "bf16x2": "--predict_pieces 2: predictions <= 1e-3 relative",
+    "bf16x1": "--predict_pieces 1: plain bf16 weights, predictions only within 2e-2 - OUTSIDE the north_star tolerance, "
+              "listed for reference, not a figure against the MFMA target",
+}
+
+
+def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
     """The only large-M contraction on the path (model.predict / --jacknife, locator.py:414, :441, :683-747):
-    a1 = ELU(BN(x) W1 + b1) for M rows at once.  flops = 2*M*K*H counted ONCE, however many bf16 pieces carry each fp32
-    weight (3 = exact products).  Two shapes: M = every row of the matrix (model.predict over all samples), and
-    M = 4096 rows drawn from it (the shape of the batched --jacknife: nboots x n_pred perturbed rows in one predict;
-    more rows per launch = fewer SNP groups = less partial-sum traffic per flop).  Per shape: image + GEMM (weights
-    converted once per sweep: us_prep, not in us; us = GEMM + its reduction, mean of `iters` back-to-back launches
-    replayed from a graph = the clocked-down sustained rate; burst_of_3 = three launches from idle) and `in_loop_conversion`
-    (loc_l1_forward_rows, which converts inside the K loop)."""
+    a1 = ELU(BN(x) W1 + b1) for M rows at once.  flops = 2*M*K*H counted ONCE, however many int8 digits or bf16 pieces
+    carry each fp32 weight; the denominator is the dense bf16-MFMA peak for every mode (int8 digits run on the i8 pipe
+    at twice the bf16 rate: 3 digits cost 1.5 bf16-MFMA equivalents per product, 2 digits 1).  Shapes: M = every row of
+    the matrix (model.predict over all samples); M = 4096 rows drawn from it (the batched --jacknife: nboots x n_pred
+    perturbed rows of the same matrix in one predict, so genotype lines repeat and come from L2 / MALL); M = 4096
+    DISTINCT rows of a second synthetic matrix (every genotype byte streams from HBM once).  Per shape and mode: us =
+    GEMM + its reduction, mean of `iters` back-to-back launches replayed from a graph (the sustained, clocked-down
+    rate); us_prep = the once-per-predict weight conversion (not in us; frac_bf16_peak_incl_prep has it); burst_of_3 =
+    three launches from idle; `in_loop_conversion` = loc_l1_forward_rows, which converts inside the K loop (few rows)."""
     import ctypes as C
 
     import torch
@@ -157,40 +174,56 @@ def l1_gemm_roofline(net, n_matrix, iters=20):
                                             P + 4 * lay.mov_var, bn4.data_ptr(), st()))
     partial = torch.empty(256 * 128 * d.Hp, device=dev)
 
-    def shape(n_rows):
-        rows = (torch.arange(n_rows, dtype=torch.int32, device=dev) % n_matrix).contiguous()
+    def shape(X, n_rows, n_src, in_loop=True):
+        rows = (torch.arange(n_rows, dtype=torch.int32, device=dev) % n_src).contiguous()
         a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
         flops = 2.0 * n_rows * d.K * d.H
-        out = {"rows": n_rows, "flops": flops}
+        out = {"rows": n_rows, "distinct_rows": min(n_rows, n_src), "flops": flops}
 
-        def rec(us, pieces, byts):
+        def rec(us, mfma_equiv, byts):
             tf = flops / us * 1e-6
             return {"us": round(us, 1), "tflops": round(tf, 1), "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
-                    "mfma_issue_frac": round(pieces * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1),
-                    "exact_fp32_products": pieces == 3}
+                    "mfma_issue_frac": round(mfma_equiv * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1)}
 
-        for pieces in (3, 1):
+        def timed(prep, run, mfma_equiv, byts):
+            prep()
+            us_prep = _time_graphed(prep, 10)
+            us = _time_graphed(run, iters)
+            r = rec(us, mfma_equiv, byts)
+            r["us_prep"] = round(us_prep, 1)
+            us_b = _time_burst(run)
+            r["burst_of_3"] = {"us": round(us_b, 1), "frac_bf16_peak": round(flops / us_b * 1e-6 / BF16_PEAK_TFLOPS, 4)}
+            r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
+            return r
+
+        for digits in (3, 2):
+            if lib.loc_l1_gemm_i8_supported(d.Hp, digits):
+                image = torch.empty(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device=dev)
+                prep = lambda: _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, digits,
+                                                                    image.data_ptr(), st()))
+                run = lambda: _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n_rows,
+                                                                    C.byref(d), image.data_ptr(), digits, 2,
+                                                                    P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
+                                                                    a1.data_ptr(), 0, st()))
+                key = "int8x%d" % digits
+                out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
+                out[key]["tolerance"] = PREDICT_MODE_INFO[key]
+                del image
+        for pieces in (3, 2, 1):
             key = "bf16x%d" % pieces
             if lib.loc_l1_gemm_supported(d.Hp, pieces):
                 image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
                 prep = lambda: _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
                                                                  image.data_ptr(), st()))
-                run = lambda: _lib.check(lib.loc_l1_forward_gemm(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(),
+                run = lambda: _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(),
                                                                  n_rows, C.byref(d), image.data_ptr(), pieces,
                                                                  P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
                                                                  a1.data_ptr(), 0, st()))
-                prep()
-                us_prep = _time_graphed(prep, 10)
-                us = _time_graphed(run, iters)
-                r = rec(us, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
-                r["us_prep"] = round(us_prep, 1)
-                us_b = _time_burst(run)
-                r["burst_of_3"] = {"us": round(us_b, 1), "frac_bf16_peak": round(flops / us_b * 1e-6 / BF16_PEAK_TFLOPS, 4)}
-                r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
-                out[key] = r
+                out[key] = timed(prep, run, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
+                out[key]["tolerance"] = PREDICT_MODE_INFO[key]
                 del image
-            if lib.loc_l1_rows_supported(d.Hp, pieces):
-                run = lambda: _lib.check(lib.loc_l1_forward_rows(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(),
+            if in_loop and pieces != 2 and lib.loc_l1_rows_supported(d.Hp, pieces):
+                run = lambda: _lib.check(lib.loc_l1_forward_rows(X.data_ptr(), X.stride(0), rows.data_ptr(),
                                                                  n_rows, C.byref(d), bn4.data_ptr(), P + 4 * lay.w1,
                                                                  P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
                                                                  a1.data_ptr(), pieces, 0, None, st()))
@@ -198,10 +231,13 @@ def l1_gemm_roofline(net, n_matrix, iters=20):
                                                                     n_rows * d.K + 4.0 * d.K * d.H)
         return out
 
-    res = shape(n_matrix)
+    res = shape(net.X, n_matrix, n_matrix)
     res["peak_tflops"] = BF16_PEAK_TFLOPS
-    res["kernel"] = "l1_gemm_kernel + l1_gemm_reduce_kernel (weights converted once per sweep by l1_image_kernel)"
-    res["jacknife_shape_4096_rows"] = shape(4096)
+    res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
+                     "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
+    res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)
+    if x_distinct is not None:
+        res["distinct_4096_rows"] = shape(x_distinct, 4096, x_distinct.shape[0], in_loop=False)
     return res
 
 
@@ -449,7 +485,13 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_l1_gemm:
-            out["l1_gemm"] = l1_gemm_roofline(fits[0].net, n)
+            # 4096 DISTINCT synthetic rows (0/1/2 genotypes drawn on the device) for the streaming shape of the GEMM
+            g = torch.Generator(device=dev).manual_seed(4096)
+            u = torch.rand((4096, fits[0].net.d.Kp), device=dev, generator=g)
+            xd = ((u < 0.25).to(torch.uint8) + (u < 0.08).to(torch.uint8)).contiguous()
+            del u
+            out["l1_gemm"] = l1_gemm_roofline(fits[0].net, n, x_distinct=xd)
+            del xd
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, np.nan_to_num(ynorm), train, test, K, H, args.cpu_seconds)
         else:

@@ -4,14 +4,53 @@
  * shuffle=1)); neither library is available here, so the published formats are restated:
  *   Blosc-1 chunk: 16-byte header {version, versionlz, flags, typesize, nbytes u32, blocksize u32, cbytes u32}
  *     flags: 0x01 byte-shuffle, 0x02 memcpy'ed, 0x04 bit-shuffle, 0x10 do-not-split, bits 5-7 codec
- *     (0 blosclz, 1 lz4/lz4hc, 2 snappy, 3 zlib, 4 zstd); then, unless memcpy'ed, nblocks int32 block offsets; every
+ *     (0 blosclz, 1 lz4/lz4hc, 2 snappy, 3 zlib, 4 zstd - read through the system's libzstd when present); then, unless memcpy'ed, nblocks int32 block offsets; every
  *     block is 1 stream or (split) `typesize` streams, each {int32 csize, data}; csize == stream size means stored.
  *   LZ4 block: sequences of {token, [literal length bytes], literals, offset u16, [match length bytes]}.
  * Pinned against the reference's own Blosc/LZ4 chunks (locator_py/map.zarr, tests/golden/blosc_*): tests/test_host.py.
  * Plain C, no device code; built into locator_amd/libloc_codecs.so by the same Makefile. */
+#include <dlfcn.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 #include <zlib.h>
+
+/* zstd payloads (Blosc codec 4, and the numcodecs "zstd" compressor): common in published Ag1000G-style stores.  The
+ * system's libzstd.so.1 is bound at first use with dlopen - the build has no zstd headers and the codecs library must
+ * still load where it is absent (-5 = not available, with a message on the Python side). */
+typedef size_t (*zstd_decompress_t)(void*, size_t, const void*, size_t);
+typedef size_t (*zstd_compress_t)(void*, size_t, const void*, size_t, int);
+typedef unsigned (*zstd_iserror_t)(size_t);
+static zstd_decompress_t z_dec;
+static zstd_compress_t z_cmp;
+static zstd_iserror_t z_err;
+static int z_state; /* 0 untried, 1 bound, -1 absent */
+static int zstd_bind(void) {
+    if (z_state == 0) {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            z_dec = (zstd_decompress_t)dlsym(h, "ZSTD_decompress");
+            z_cmp = (zstd_compress_t)dlsym(h, "ZSTD_compress");
+            z_err = (zstd_iserror_t)dlsym(h, "ZSTD_isError");
+        }
+        z_state = (z_dec && z_cmp && z_err) ? 1 : -1;
+    }
+    return z_state == 1;
+}
+int loc_zstd_available(void) { return zstd_bind(); }
+/* one zstd frame -> dst; bytes written, -1 malformed / too small, -5 no libzstd */
+int64_t loc_zstd_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
+    if (!zstd_bind()) return -5;
+    const size_t n = z_dec(dst, (size_t)dst_cap, src, (size_t)src_len);
+    return z_err(n) ? -1 : (int64_t)n;
+}
+/* writer side, for test / synthetic stores only */
+int64_t loc_zstd_compress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap, int level) {
+    if (!zstd_bind()) return -5;
+    const size_t n = z_cmp(dst, (size_t)dst_cap, src, (size_t)src_len, level);
+    return z_err(n) ? -1 : (int64_t)n;
+}
 
 static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
@@ -56,7 +95,8 @@ static int64_t inflate_to(const uint8_t* src, int64_t src_len, uint8_t* dst, int
 /* Decode one Blosc-1 chunk.  split_mode: 0 = follow the header, 1 = force split streams, 2 = force unsplit (older
  * writers decide the split without recording it; the caller retries).  tmp: at least `blocksize` bytes (see
  * loc_blosc1_info).  Returns the decompressed byte count (== header nbytes) or a negative error:
- *   -1 malformed, -2 unsupported codec, -3 unsupported filter (bit-shuffle), -4 output buffer too small. */
+ *   -1 malformed, -2 unsupported codec (blosclz, snappy), -3 unsupported filter (bit-shuffle), -4 output buffer too
+ *   small, -5 zstd payload but no libzstd on this machine. */
 int64_t loc_blosc1_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap, uint8_t* tmp,
                               int split_mode) {
     if (src_len < 16) return -1;
@@ -72,7 +112,8 @@ int64_t loc_blosc1_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst,
     }
     if (flags & 0x04) return -3;
     const unsigned codec = flags >> 5;
-    if (codec != 1 && codec != 3) return -2;
+    if (codec != 1 && codec != 3 && codec != 4) return -2;
+    if (codec == 4 && !zstd_bind()) return -5;
     if (blocksize <= 0) return -1;
     const int shuffle = (flags & 0x01) && typesize > 1;
     const int64_t nblocks = (nbytes + blocksize - 1) / blocksize;
@@ -93,8 +134,9 @@ int64_t loc_blosc1_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst,
             if (cs < 0 || pos + cs > src_len) return -1;
             if (cs == ssize) memcpy(out + s * ssize, src + pos, (size_t)ssize);
             else {
-                const int64_t got = codec == 1 ? loc_lz4_decompress(src + pos, cs, out + s * ssize, ssize)
-                                                : inflate_to(src + pos, cs, out + s * ssize, ssize);
+                const int64_t got = codec == 1   ? loc_lz4_decompress(src + pos, cs, out + s * ssize, ssize)
+                                    : codec == 3 ? inflate_to(src + pos, cs, out + s * ssize, ssize)
+                                                 : loc_zstd_decompress(src + pos, cs, out + s * ssize, ssize);
                 if (got != ssize) return -1;
             }
             pos += cs;

@@ -107,13 +107,50 @@ def _codecs():
         lib.loc_blosc1_info.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
         lib.loc_lz4_decompress.restype = C.c_int64
         lib.loc_lz4_decompress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.loc_zstd_available.restype = C.c_int
+        lib.loc_zstd_decompress.restype = C.c_int64
+        lib.loc_zstd_decompress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.loc_zstd_compress.restype = C.c_int64
+        lib.loc_zstd_compress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]
         _CODECS = lib
     return _CODECS
 
 
+NO_ZSTD = ("this store's chunks are zstd-compressed and libzstd.so.1 was not found on this machine; install the zstd "
+           "runtime library (libzstd1) or re-encode the store with Blosc(cname='lz4') / zlib")
+
+
+def zstd_available():
+    return bool(_codecs().loc_zstd_available())
+
+
+def zstd_decompress(raw, nbytes):
+    """One zstd frame of known decoded size (the numcodecs `zstd` compressor; also the payload of Blosc codec 4)."""
+    out = np.empty(max(int(nbytes), 1), np.uint8)
+    r = _codecs().loc_zstd_decompress(bytes(raw), len(raw), out.ctypes.data, int(nbytes))
+    if r == -5:
+        raise RuntimeError(NO_ZSTD)
+    if r != nbytes:
+        raise ValueError("malformed zstd chunk")
+    return out[:nbytes].tobytes()
+
+
+def zstd_compress(raw, level=3):
+    """Writer side, for test / synthetic stores only."""
+    raw = bytes(raw)
+    out = np.empty(len(raw) + len(raw) // 128 + 256, np.uint8)
+    r = _codecs().loc_zstd_compress(raw, len(raw), out.ctypes.data, out.size, int(level))
+    if r == -5:
+        raise RuntimeError(NO_ZSTD)
+    if r < 0:
+        raise ValueError("zstd compression failed")
+    return out[:r].tobytes()
+
+
 def blosc_decompress(raw):
     """One Blosc-1 chunk (what numcodecs.Blosc / `allel.vcf_to_zarr` write by default: LZ4, byte-shuffle) -> bytes.
-    Codecs: lz4 / lz4hc, zlib, stored; filters: byte-shuffle.  zstd / blosclz / bit-shuffle raise."""
+    Codecs: lz4 / lz4hc, zlib, zstd (through the system's libzstd), stored; filters: byte-shuffle.  blosclz /
+    bit-shuffle raise."""
     import ctypes as C
     lib = _codecs()
     info = (C.c_int64 * 5)()
@@ -126,8 +163,10 @@ def blosc_decompress(raw):
         r = lib.loc_blosc1_decompress(raw, len(raw), out.ctypes.data, nbytes, tmp.ctypes.data, mode)
         if r == nbytes:
             return out.tobytes()
+        if r == -5:
+            raise RuntimeError(NO_ZSTD)
         if r in (-2, -3):
-            what = "codec (supported: lz4, zlib, stored)" if r == -2 else "filter bit-shuffle"
+            what = "codec (supported: lz4, zlib, zstd, stored)" if r == -2 else "filter bit-shuffle"
             raise ValueError(f"blosc chunk uses an unsupported {what}; re-encode the store with "
                              "Blosc(cname='lz4') or zlib")
     raise ValueError("malformed blosc chunk")
@@ -183,15 +222,15 @@ def _lz4_compress_block(data):
     return bytes(out)
 
 
-def blosc_compress(raw, typesize=1, shuffle=True, blocksize=1 << 16):
-    """Blosc-1 chunk with LZ4 streams and byte-shuffle, laid out as c-blosc writes it (16-byte header, block offsets,
-    per-stream {int32 size, data}, split into `typesize` streams when the block is large enough)."""
+def blosc_compress(raw, typesize=1, shuffle=True, blocksize=1 << 16, cname="lz4"):
+    """Blosc-1 chunk with LZ4 (or zstd) streams and byte-shuffle, laid out as c-blosc writes it (16-byte header, block
+    offsets, per-stream {int32 size, data}, split into `typesize` streams when the block is large enough)."""
     raw = bytes(raw)
     nbytes = len(raw)
     typesize = max(1, int(typesize))
     blocksize = max(typesize, min(blocksize, nbytes) // typesize * typesize) if nbytes else typesize
     do_shuffle = shuffle and typesize > 1
-    flags = (1 << 5) | (1 if do_shuffle else 0)
+    flags = ({"lz4": 1, "zstd": 4}[cname] << 5) | (1 if do_shuffle else 0)
     nblocks = (nbytes + blocksize - 1) // blocksize if nbytes else 0
     body, starts = bytearray(), []
     pos = 16 + 4 * nblocks
@@ -209,7 +248,7 @@ def blosc_compress(raw, typesize=1, shuffle=True, blocksize=1 << 16):
         starts.append(pos)
         for k in range(ns):
             stream = arr[k * ss:(k + 1) * ss]
-            comp = _lz4_compress_block(stream)
+            comp = _lz4_compress_block(stream) if cname == "lz4" else zstd_compress(stream)
             if len(comp) >= len(stream):
                 comp = stream                                    # stored
             body += len(comp).to_bytes(4, "little") + comp
@@ -240,9 +279,9 @@ class ZarrArray:
         self.sep = meta.get("dimension_separator", ".")
         self.ndim = len(self.shape)
         self.vlen_utf8 = any(f.get("id") == "vlen-utf8" for f in self.filters)
-        if self.compressor is not None and self.compressor.get("id") not in ("zlib", "gzip", "blosc"):
+        if self.compressor is not None and self.compressor.get("id") not in ("zlib", "gzip", "blosc", "zstd"):
             raise ValueError(f"{path}: compressor {self.compressor.get('id')!r} is not supported here "
-                             "(supported: null, zlib, gzip, blosc)")
+                             "(supported: null, zlib, gzip, blosc, zstd)")
 
     def __len__(self):
         return self.shape[0]
@@ -250,6 +289,10 @@ class ZarrArray:
     def _decode(self, raw, cshape):
         if self.compressor is not None and self.compressor.get("id") == "blosc":
             raw = blosc_decompress(raw)
+        elif self.compressor is not None and self.compressor.get("id") == "zstd":
+            if self.vlen_utf8:
+                raise ValueError(f"{self.path}: zstd-compressed string arrays are not supported")
+            raw = zstd_decompress(raw, int(np.prod(cshape)) * self.dtype.itemsize)
         elif self.compressor is not None:
             raw = zlib.decompress(raw, 15 + 32)        # auto-detect zlib / gzip framing
         if self.vlen_utf8:
@@ -337,15 +380,17 @@ def open_group(path, mode="r"):
 
 
 def write_zarr_array(path, arr, chunks, compressor=None):
-    """Minimal zarr-v2 writer (uncompressed, zlib, or "blosc" = Blosc-1 / LZ4 / byte-shuffle as `allel.vcf_to_zarr`
-    writes by default) used to build synthetic stores (config 4) and test fixtures."""
+    """Minimal zarr-v2 writer (uncompressed, zlib, "blosc" = Blosc-1 / LZ4 / byte-shuffle as `allel.vcf_to_zarr` writes
+    by default, "blosc-zstd" = the same container with zstd streams, "zstd" = numcodecs' plain zstd frames) used to
+    build synthetic stores (config 4) and test fixtures."""
     arr = np.asarray(arr)
     os.makedirs(path, exist_ok=True)
     chunks = tuple(int(min(c, s)) if s else 1 for c, s in zip(chunks, arr.shape))
     meta = {"zarr_format": 2, "shape": list(arr.shape), "chunks": list(chunks), "dtype": arr.dtype.str,
-            "compressor": ({"id": "zlib", "level": 1} if compressor == "zlib" else
-                           {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
-                           if compressor == "blosc" else None), "fill_value": 0,
+            "compressor": {None: None, "zlib": {"id": "zlib", "level": 1},
+                           "blosc": {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0},
+                           "blosc-zstd": {"id": "blosc", "cname": "zstd", "clevel": 5, "shuffle": 1, "blocksize": 0},
+                           "zstd": {"id": "zstd", "level": 3}}[compressor], "fill_value": 0,
             "order": "C", "filters": None}
     with open(os.path.join(path, ".zarray"), "w") as fh:
         json.dump(meta, fh)
@@ -360,6 +405,10 @@ def write_zarr_array(path, arr, chunks, compressor=None):
             raw = zlib.compress(raw, 1)
         elif compressor == "blosc":
             raw = blosc_compress(raw, arr.dtype.itemsize)
+        elif compressor == "blosc-zstd":
+            raw = blosc_compress(raw, arr.dtype.itemsize, cname="zstd")
+        elif compressor == "zstd":
+            raw = zstd_compress(raw)
         with open(os.path.join(path, ".".join(map(str, idx))), "wb") as fh:
             fh.write(raw)
 
