@@ -18,7 +18,7 @@ Deliberate, documented deviations:
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 128 rows (the reference default is 32; 33..128 needs a --width that pads to 64,
     128 or 256 and --nlayers >= 4 with dropout), --nlayers must be >= 2 and --width <= 512;
-  * extra flags --gpus / --fits_per_gpu / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
+  * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """
 from __future__ import annotations
@@ -81,6 +81,9 @@ def build_parser():
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
     p.add_argument("--fits_per_gpu", default=2, type=int,
                    help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
+    p.add_argument("--unit_timeout", default=0, type=float,
+                   help="seconds one --windows / --bootstrap replicate may take inside a worker before that worker is "
+                        "killed and replaced and the replicate reported as failed (default 0: no limit)")
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
     p.add_argument("--load_weights", default=None, type=str,
                    help="a .weights.npz written by --keep_weights: skip training and predict with these weights")
@@ -430,8 +433,10 @@ def _fit_unit(unit, device="cuda:0"):
     from .net import gather_columns, upload_genotypes
     args = unit["args"]
     t_unit = time.time()
+    phases = {}
     if "window" in unit:
-        _load_window(unit)
+        _load_window(unit)          # a no-op when the worker's loader thread has already done it (host_prepare)
+    phases["load"] = time.time() - t_unit
     tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
     ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
     key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
@@ -444,6 +449,7 @@ def _fit_unit(unit, device="cuda:0"):
             _BASE_CACHE[key] = X
     if unit.get("site_order") is not None:
         X = gather_columns(X, unit["site_order"], K)
+    phases["upload"] = time.time() - t_unit - phases["load"]
     traingen, testgen = DeviceRows(X, 0, ntr, K), DeviceRows(X, ntr, nva, K)
     predgen = DeviceRows(X, ntr + nva, npr, K)
     model = load_network(traingen, args.dropout_prop, replicate=unit["replicate"], device=device)
@@ -453,13 +459,26 @@ def _fit_unit(unit, device="cuda:0"):
     args.out = unit["out"]
     try:
         callbacks = load_callbacks(unit["boot"])
+        t1 = time.time()
         history, model = train_network(model, traingen, testgen, unit["trainlocs"], unit["testlocs"], callbacks,
                                        unit["boot"])
+        phases["fit"] = time.time() - t1
+        t1 = time.time()
         dists = predict_locs(model, predgen, unit["sdlong"], unit["meanlong"], unit["sdlat"], unit["meanlat"],
                              unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
+        phases["predict"] = time.time() - t1
     finally:
         args.out = original_out
-    return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t_unit}
+    return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t_unit,
+            "phases": phases, "epochs": len(history.history.get("loss", []))}
+
+
+def _load_window_on_loader_thread(unit, a):
+    """ReplicatePool host_prepare hook: the zarr slice + filters of a window, run by the worker's loader thread while the
+    previous window is still fitting (they used to sit on every fit's critical path, locator.py:539-545)."""
+    u = dict(unit)
+    u["args"] = a
+    return _load_window(u)
 
 
 def _window_bounds():
@@ -572,10 +591,39 @@ def _prologue(force_full=False):
 
 
 # ------------------------------------------------------------------ main (locator.py:487-749)
+def _print_replicate_summary(pool, results, t_program):
+    """Per-phase means over the units, the scheduler's timeline and its Amdahl projection (replicates.ReplicatePool)."""
+    ok = [r for r in results if r is not None and "error" not in r and "phases" in r]
+    if ok:
+        mean = lambda k: sum(r["phases"].get(k, 0.0) for r in ok) / len(ok)
+        host = sum(r.get("host_prepare_seconds", 0.0) for r in ok) / len(ok)
+        print(f"replicate phases, mean of {len(ok)} units: host slice+filter {host:.2f} s (loader thread), load-in-fit "
+              f"{mean('load'):.2f} s, upload {mean('upload'):.2f} s, fit {mean('fit'):.2f} s, predict {mean('predict'):.2f} s")
+    for line in pool.summary(results, program_started=t_program)["lines"]:
+        print(line)
+
+
 def main(argv=None):
+    t_program = time.time()
     _setup(argv)
     from . import replicates
 
+    pool = None
+    if args.windows or args.bootstrap:
+        # the worker processes start NOW: spawn + `import torch` + device context + library load overlap the parent's
+        # own prologue instead of following it
+        lazy_windows = args.windows and not args.impute_missing and args.max_SNPs is None
+        pool = replicates.ReplicatePool(args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu,
+                                        host_prepare=_load_window_on_loader_thread if lazy_windows else None,
+                                        unit_timeout=getattr(args, "unit_timeout", 0)).start()
+    try:
+        return _main_body(pool, t_program)
+    finally:
+        if pool is not None:
+            pool.close()
+
+
+def _main_body(pool, t_program):
     samples, state = _prologue()
     if state is not None:
         (meanlong, sdlong, meanlat, sdlat, ac, train, test, traingen, testgen, trainlocs, testlocs, pred,
@@ -584,7 +632,8 @@ def main(argv=None):
     failed = 0
     if args.windows:
         units = _window_units(samples)
-        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu)
+        results = pool.run(units)
+        _print_replicate_summary(pool, results, t_program)
         for r in results:
             if "error" in r:
                 print(f"{r['name']}: FAILED: {r['error']}")
@@ -605,8 +654,8 @@ def main(argv=None):
         shared = dict(traingen=np.ascontiguousarray(traingen), testgen=np.ascontiguousarray(testgen),
                       predgen=np.ascontiguousarray(predgen), trainlocs=trainlocs, testlocs=testlocs, pred=pred,
                       samples=samples, sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, out=args.out)
-        results = replicates.run_units(units, args, _fit_unit, n_gpus=args.gpus, shared=shared,
-                                       fits_per_gpu=args.fits_per_gpu)
+        results = pool.run(units, shared)
+        _print_replicate_summary(pool, results, t_program)
         failed = sum("error" in r for r in results)
         # {out}_history.txt / fitplot are overwritten by every replicate in the reference: last one wins
         results = [r for r in results if "error" not in r]

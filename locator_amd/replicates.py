@@ -73,36 +73,78 @@ def _attach(small, descs):
     return out, keep
 
 
-def _worker(gpu, fit_fn, small, descs, args, prepare, conn):
+def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent):
     """Worker process on its own duplex pipe (no queue or lock is shared between workers, so one that is killed
-    cannot wedge the others): receives (index, unit), sends back the result record, exits on None."""
+    cannot wedge the others).  Start-up (import torch, device context, HIP library) happens right away - the parent
+    spawns the pool BEFORE its own prologue so that the two overlap.  Messages in: ("shared", small, descs) once,
+    ("unit", index, unit) per unit, None to exit.  A loader thread receives them and runs `host_prepare` (the
+    zarr slice + filters of a window) for the NEXT unit while the main thread fits the current one; messages out:
+    ("ready", info), ("start", index), ("done", record) - only the main thread sends, only the loader receives."""
+    import queue
+    import threading
+    import time
+    t0 = time.time()
     try:
         import torch
         if torch.cuda.is_available():
             torch.cuda.set_device(gpu)
             device = f"cuda:{gpu}"
+            torch.zeros(1, device=device)                       # device context now, not inside the first fit
+            from . import _lib
+            _lib.load()
         else:               # scheduler tests on CPU; a real fit_fn raises on this device (no CPU fallback)
             device = "cpu"
-        shared, keep = _attach(small, descs)
     except Exception as e:                                   # noqa: BLE001 - the parent turns it into error records
         conn.send(("dead", f"worker start-up failed: {type(e).__name__}: {e}"))
         return
-    conn.send(("ready", None))
+    conn.send(("ready", {"startup_seconds": time.time() - t0, "spawn_seconds": t0 - t_parent, "ready_at": time.time()}))
+    todo = queue.Queue()
+    box = {"shared": {}, "keep": []}
+
+    def loader():
+        while True:
+            try:
+                item = conn.recv()
+            except (EOFError, OSError):
+                item = None
+            if item is None:
+                todo.put(None)
+                return
+            if item[0] == "shared":
+                box["shared"], box["keep"] = _attach(item[1], item[2])
+                continue
+            _, idx, unit = item
+            t1, err = time.time(), None
+            try:
+                if host_prepare is not None:
+                    unit = host_prepare(unit, args)
+            except Exception as e:                           # noqa: BLE001
+                err = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
+                       "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
+            todo.put((idx, unit, err, time.time() - t1))
+
+    threading.Thread(target=loader, daemon=True).start()
     while True:
-        item = conn.recv()
+        item = todo.get()
         if item is None:
             break
-        idx, unit = item
-        try:
-            if prepare is not None:
-                unit = prepare(unit)
-            r = _run_one(fit_fn, unit, shared, args, device)
-        except Exception as e:                               # noqa: BLE001 - e.g. prepare() raising
-            r = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
-                 "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
+        idx, unit, err, t_host = item
+        conn.send(("start", idx))
+        t1 = time.time()
+        if err is not None:
+            r = err
+        else:
+            try:
+                if prepare is not None:
+                    unit = prepare(unit)
+                r = _run_one(fit_fn, unit, box["shared"], args, device)
+            except Exception as e:                           # noqa: BLE001 - e.g. prepare() raising
+                r = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
+                     "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
         r["unit_index"], r["gpu"] = idx, gpu
+        r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t1
         conn.send(("done", r))
-    for shm in keep:
+    for shm in box["keep"]:
         shm.close()
 
 
@@ -111,127 +153,305 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print, fits_per_gpu=1, poll_s=1.0):
-    """Run every unit once; returns the result records in unit order.
+class ReplicatePool:
+    """The replicate scheduler: worker processes (one or more per GPU), dynamic dispatch, a timeline.
 
-    units         list of dicts (small per-unit data; window units carry their own genotype slices)
-    shared        dict of data common to all units; NumPy arrays of >= 1 MB are placed in shared memory once and
-                  attached by every worker (the 0.5 GB bootstrap matrix is not pickled 16 times)
-    prepare       optional per-unit hook run in the worker before fit_fn (e.g. column resampling)
+        pool = ReplicatePool(args, fit_fn, n_gpus=8, fits_per_gpu=2, host_prepare=load_window)
+        pool.start()                     # BEFORE the parent's own prologue: spawn + import torch + device context overlap it
+        ... parent prologue (draw splits, read sample table, ...) ...
+        records = pool.run(units, shared)
+        pool.close(); print(pool.summary())
+
     fits_per_gpu  worker processes per GPU.  A single fit alternates between an HBM-bound phase (layer 1) and a
                   latency-bound phase (hidden stack, 16 CUs); two fits on one GPU interleave them: measured 209k
                   vs 157k samples/s aggregate on the 1000 x 100k workload (1.33x), no further gain from a third.
+    prepare       optional per-unit hook run in the worker's main thread right before fit_fn (device-side work)
+    host_prepare  optional per-unit hook `f(unit, args) -> unit` run on a LOADER THREAD of the worker: the parent keeps
+                  two units in flight per worker, so the host work of unit i + 1 (zarr slice + filters, 2 s per
+                  150k-variant window) overlaps the fit of unit i instead of sitting on its critical path
+    unit_timeout  seconds a unit may spend in a worker after it reported ("start", i); a worker that exceeds it is
+                  killed (its exact process, never a pattern), the unit becomes an error record and a FRESH process
+                  takes the slot - a hung (not dead) worker no longer blocks the run.  0 = no limit.
 
-    Dynamic dispatch: the parent hands the next unit to whichever worker is idle (early stopping makes unit durations
+    Dynamic dispatch: the parent hands the next unit to whichever worker has room (early stopping makes unit durations
     vary several-fold).  A worker that dies (GPU fault, OOM kill, abort) does not hang the run: its pipe reports
-    end-of-file, the parent records an error for the unit it was holding and starts a FRESH process in its place
-    (never re-executes the dead one) while units remain."""
-    n_vis = visible_gpus()
-    n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
-    n = max(1, min(n_g * max(1, int(fits_per_gpu)), len(units)))
-    out = [None] * len(units)
-    if n <= 1:
-        for i, u in enumerate(units):
-            try:
-                if prepare is not None:
-                    u = prepare(u)
-                r = _run_one(fit_fn, u, shared, args, "cuda:0")
-            except Exception as e:                           # noqa: BLE001
-                r = {"name": u.get("name", "?"), "error": f"{type(e).__name__}: {e}",
-                     "traceback": traceback.format_exc()}
-            r["unit_index"], r["gpu"] = i, 0
-            out[i] = r
-            if "error" in r:
-                log(f"replicate {r['name']} FAILED: {r['error']}")
-        return out
-    from multiprocessing.connection import wait
+    end-of-file, the parent records an error for the unit it was fitting, puts units it had only prefetched back in
+    the queue, and starts a fresh process while units remain.  A send that fails because the worker vanished between
+    two messages requeues the unit the same way."""
 
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    small, descs, handles = _share(shared)
-    workers = {}                            # parent end of the pipe -> [process, gpu, unit index in flight or None, ready]
-    state = {"got": 0, "next": 0, "failed_starts": 0}
+    def __init__(self, args, fit_fn, n_gpus=None, fits_per_gpu=1, prepare=None, host_prepare=None, log=print,
+                 poll_s=1.0, unit_timeout=0.0, max_workers=None):
+        import time
+        self.args, self.fit_fn, self.prepare, self.host_prepare = args, fit_fn, prepare, host_prepare
+        self.log, self.poll_s, self.unit_timeout = log, poll_s, float(unit_timeout or 0.0)
+        n_vis = visible_gpus()
+        self.n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
+        self.n = max(1, self.n_g * max(1, int(fits_per_gpu)))
+        if max_workers is not None:
+            self.n = max(1, min(self.n, int(max_workers)))
+        self.depth = 2 if host_prepare is not None else 1
+        self.workers = {}                   # parent end of the pipe -> state dict
+        self.ctx = None
+        self.t0 = time.time()
+        self.timeline = {"pool_created": self.t0, "workers": [], "units": {}, "n_workers": self.n, "n_gpus": self.n_g}
+        self.failed_starts = 0
+        self._slot = 0
 
-    def start_worker(gpu):
-        a, b = ctx.Pipe(duplex=True)
-        p = ctx.Process(target=_worker, args=(gpu, fit_fn, small, descs, args, prepare, b), daemon=True)
+    # ------------------------------------------------------------------ processes
+    def start(self):
+        """Spawn the workers now (no-op for a single in-process worker).  Returns self."""
+        if self.n <= 1 or self.workers:
+            return self
+        import torch.multiprocessing as mp
+        self.ctx = mp.get_context("spawn")
+        for w in range(self.n):
+            self._start_worker(w % self.n_g)
+        return self
+
+    def _start_worker(self, gpu):
+        import time
+        a, b = self.ctx.Pipe(duplex=True)
+        t = time.time()
+        p = self.ctx.Process(target=_worker, args=(gpu, self.fit_fn, self.args, self.prepare, self.host_prepare, b, t),
+                             daemon=True)
         p.start()
         b.close()                           # the parent keeps only its own end: EOF then means "the worker is gone"
-        workers[a] = [p, gpu, None, False]
+        self.workers[a] = {"p": p, "gpu": gpu, "inflight": [], "active": None, "t_active": 0.0, "ready": False,
+                           "shared_sent": False, "t_spawn": t, "slot": self._slot}
+        self._slot += 1
 
-    def record(r):
-        if out[r["unit_index"]] is None:
-            out[r["unit_index"]] = r
-            state["got"] += 1
-            if "error" in r:
-                log(f"replicate {r['name']} FAILED on GPU {r['gpu']}: {r['error']}")
-            else:
-                log(f"replicate {r['name']} done on GPU {r['gpu']} in {r.get('seconds', 0):.1f} s")
+    # ------------------------------------------------------------------ the run
+    def run(self, units, shared=None):
+        """Run every unit once; returns the result records in unit order."""
+        import time
+        tl = self.timeline
+        tl["run_started"] = time.time()
+        out = [None] * len(units)
+        if self.n <= 1 or len(units) <= 1 and not self.workers:
+            # one worker = this process; the host work of unit i + 1 still overlaps the fit of unit i (one loader thread)
+            from concurrent.futures import ThreadPoolExecutor
 
-    def feed(conn):
-        w = workers[conn]
-        if w[3] and w[2] is None and state["next"] < len(units):
-            i = state["next"]
-            state["next"] += 1
-            w[2] = i
-            conn.send((i, units[i]))
-
-    def bury(conn, why):
-        p, gpu, idx, _ = workers.pop(conn)
-        conn.close()
-        p.join(5)
-        if idx is not None and out[idx] is None:
-            record({"name": units[idx].get("name", "?"), "unit_index": idx, "gpu": gpu,
-                    "error": f"worker process died ({why}, exit code {p.exitcode}) while fitting this unit"})
-        elif idx is None and why != "retired":
-            state["failed_starts"] += 1
-        if state["got"] < len(units) and state["next"] < len(units) and state["failed_starts"] < 4 * n:
-            start_worker(gpu)
-
-    try:
-        for w in range(n):
-            start_worker(w % n_g)
-        while state["got"] < len(units):
-            if not workers:                 # every start-up failed repeatedly: report what is left and stop
-                for i, r in enumerate(out):
-                    if r is None:
-                        record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": -1,
-                                "error": "no worker process could be started"})
-                break
-            for conn in wait(list(workers), timeout=poll_s):
+            def host(u):
+                t1 = time.time()
                 try:
-                    kind, payload = conn.recv()
-                except (EOFError, OSError):
-                    bury(conn, "pipe closed")
+                    return (self.host_prepare(u, self.args) if self.host_prepare is not None else u), None, time.time() - t1
+                except Exception as e:                       # noqa: BLE001
+                    return u, {"name": u.get("name", "?"), "error": f"{type(e).__name__}: {e}",
+                               "traceback": traceback.format_exc()}, time.time() - t1
+            with ThreadPoolExecutor(1) as ex:
+                nxt = ex.submit(host, units[0]) if units else None
+                for i in range(len(units)):
+                    t1 = time.time()
+                    u, err, t_host = nxt.result()
+                    nxt = ex.submit(host, units[i + 1]) if i + 1 < len(units) else None
+                    t2 = time.time()
+                    if err is not None:
+                        r = err
+                    else:
+                        try:
+                            if self.prepare is not None:
+                                u = self.prepare(u)
+                            r = _run_one(self.fit_fn, u, shared, self.args, "cuda:0")
+                        except Exception as e:               # noqa: BLE001
+                            r = {"name": u.get("name", "?"), "error": f"{type(e).__name__}: {e}",
+                                 "traceback": traceback.format_exc()}
+                    r["unit_index"], r["gpu"] = i, 0
+                    r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t2
+                    out[i] = r
+                    tl["units"][i] = {"gpu": 0, "dispatched": t1, "started": t2, "done": time.time()}
+                    if "error" in r:
+                        self.log(f"replicate {r['name']} FAILED: {r['error']}")
+            tl["run_finished"] = time.time()
+            return out
+        from collections import deque
+        from multiprocessing.connection import wait
+        self.start()
+        small, descs, handles = _share(shared)
+        workers = self.workers
+        state = {"got": 0, "next": 0}
+        retry, attempts = deque(), {}
+
+        def record(r):
+            i = r["unit_index"]
+            if out[i] is None:
+                out[i] = r
+                state["got"] += 1
+                tl["units"].setdefault(i, {})["done"] = time.time()
+                if "error" in r:
+                    self.log(f"replicate {r['name']} FAILED on GPU {r['gpu']}: {r['error']}")
+                else:
+                    self.log(f"replicate {r['name']} done on GPU {r['gpu']} in {r.get('seconds', 0):.1f} s")
+
+        def next_index():
+            while retry:
+                i = retry.popleft()
+                if out[i] is None:
+                    return i
+            if state["next"] < len(units):
+                state["next"] += 1
+                return state["next"] - 1
+            return None
+
+        def feed(conn):
+            w = workers.get(conn)
+            if w is None or not w["ready"]:
+                return
+            try:
+                if not w["shared_sent"]:
+                    conn.send(("shared", small, descs))
+                    w["shared_sent"] = True
+                while len(w["inflight"]) < self.depth:
+                    i = next_index()
+                    if i is None:
+                        return
+                    w["inflight"].append(i)
+                    attempts[i] = attempts.get(i, 0) + 1
+                    tl["units"].setdefault(i, {}).update(gpu=w["gpu"], dispatched=time.time())
+                    conn.send(("unit", i, units[i]))
+            except (OSError, ValueError):        # the worker vanished between two messages: its units go back
+                bury(conn, "pipe closed")
+
+        def bury(conn, why):
+            w = workers.pop(conn, None)
+            if w is None:
+                return
+            try:
+                conn.close()
+            except OSError:
+                pass
+            w["p"].join(5)
+            victim = w["active"] if w["active"] is not None else (w["inflight"][0] if w["inflight"] else None)
+            for i in w["inflight"]:
+                if out[i] is not None:
                     continue
-                if kind == "ready":
-                    workers[conn][3] = True
-                elif kind == "done":
-                    workers[conn][2] = None
-                    record(payload)
-                elif kind == "dead":
-                    log(f"replicate worker on GPU {workers[conn][1]}: {payload}")
-                    bury(conn, "start-up failure")
-                    continue
-                feed(conn)
-            for conn in list(workers):      # belt and braces: a process can be gone before its pipe says so
-                if not workers[conn][0].is_alive() and not conn.poll():
-                    bury(conn, "not alive")
-        for conn, w in list(workers.items()):
+                if i == victim or attempts.get(i, 0) >= 2:
+                    record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": w["gpu"],
+                            "error": f"worker process died ({why}, exit code {w['p'].exitcode}) while fitting this unit"})
+                else:
+                    retry.append(i)                      # only prefetched, never started: another worker takes it
+            if not w["inflight"] and why not in ("retired",):
+                self.failed_starts += 1
+            if state["got"] < len(units) and (retry or state["next"] < len(units)) and self.failed_starts < 4 * self.n:
+                self._start_worker(w["gpu"])
+
+        try:
+            while state["got"] < len(units):
+                if not workers:                 # every start-up failed repeatedly: report what is left and stop
+                    for i, r in enumerate(out):
+                        if r is None:
+                            record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": -1,
+                                    "error": "no worker process could be started"})
+                    break
+                for conn in wait(list(workers), timeout=self.poll_s):
+                    if conn not in workers:
+                        continue
+                    try:
+                        kind, payload = conn.recv()
+                    except (EOFError, OSError):
+                        bury(conn, "pipe closed")
+                        continue
+                    w = workers[conn]
+                    if kind == "ready":
+                        w["ready"] = True
+                        info = dict(payload or {})
+                        tl["workers"].append({"slot": w["slot"], "gpu": w["gpu"], "spawned": w["t_spawn"],
+                                              "ready": info.pop("ready_at", time.time()), **info})
+                    elif kind == "start":
+                        w["active"], w["t_active"] = payload, time.time()
+                        tl["units"].setdefault(payload, {})["started"] = w["t_active"]
+                    elif kind == "done":
+                        if payload["unit_index"] in w["inflight"]:
+                            w["inflight"].remove(payload["unit_index"])
+                        w["active"] = None
+                        record(payload)
+                    elif kind == "dead":
+                        self.log(f"replicate worker on GPU {w['gpu']}: {payload}")
+                        bury(conn, "start-up failure")
+                        continue
+                    feed(conn)
+                now = time.time()
+                for conn in list(workers):      # belt and braces: a process can be gone before its pipe says so
+                    w = workers[conn]
+                    if not w["p"].is_alive() and not conn.poll():
+                        bury(conn, "not alive")
+                    elif self.unit_timeout and w["active"] is not None and now - w["t_active"] > self.unit_timeout:
+                        self.log(f"replicate {units[w['active']].get('name', '?')} on GPU {w['gpu']} exceeded "
+                                 f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
+                        w["p"].kill()               # this exact process
+                        bury(conn, f"timed out after {self.unit_timeout:g} s")
+        finally:
+            for shm in handles:
+                shm.close()
+                shm.unlink()
+        tl["run_finished"] = time.time()
+        return out
+
+    def close(self):
+        for conn, w in list(self.workers.items()):
             try:
                 conn.send(None)
             except (OSError, ValueError):
                 pass
-        for conn, w in list(workers.items()):
-            w[0].join(30)
-            if w[0].is_alive():
-                w[0].terminate()
-            conn.close()
+        for conn, w in list(self.workers.items()):
+            w["p"].join(30)
+            if w["p"].is_alive():
+                w["p"].terminate()
+            try:
+                conn.close()
+            except OSError:
+                pass
+        self.workers = {}
+
+    # ------------------------------------------------------------------ what happened, and what N GPUs would do
+    def summary(self, records=None, program_started=None):
+        """Phase timeline of the run as a dict (and `lines` for printing): parent time before the dispatch loop,
+        worker start-up (and how much of it the parent's prologue hid), per-unit host / fit seconds, the part of the
+        wall time that the parallel work does not explain (serial fraction), and the Amdahl projection for 1..8 GPUs at
+        the same workers per GPU: T(g) = serial + unit_work / (g * workers_per_gpu), unit_work = sum of worker seconds."""
+        tl = self.timeline
+        t_prog = program_started if program_started is not None else tl["pool_created"]
+        t_run0, t_run1 = tl.get("run_started", tl["pool_created"]), tl.get("run_finished", tl["pool_created"])
+        wall = t_run1 - t_prog
+        recs = [r for r in (records or []) if r is not None]
+        work = sum(r.get("worker_seconds", 0.0) for r in recs)
+        host = sum(r.get("host_prepare_seconds", 0.0) for r in recs)
+        ready = [w["ready"] for w in tl["workers"]]
+        startup = [w.get("startup_seconds", 0.0) + w.get("spawn_seconds", 0.0) for w in tl["workers"]]
+        first_ready = (min(ready) - t_prog) if ready else 0.0
+        n_w = max(1, min(self.n, len(recs)) if recs else self.n)
+        per_gpu = max(1, self.n // self.n_g)
+        serial = max(0.0, wall - work / n_w)
+        s = {"wall_seconds": wall, "parent_prologue_seconds": t_run0 - t_prog, "dispatch_loop_seconds": t_run1 - t_run0,
+             "workers": self.n, "gpus": self.n_g, "worker_startup_seconds_mean": (sum(startup) / len(startup)) if startup else 0.0,
+             "first_worker_ready_after_seconds": first_ready, "units": len(recs), "unit_work_seconds": work,
+             "host_prepare_seconds_total": host, "serial_seconds": serial, "serial_fraction": serial / wall if wall > 0 else 0.0,
+             "amdahl_projection_seconds": {g: serial + work / (g * per_gpu) for g in (1, 2, 4, 8)}}
+        s["amdahl_speedup_vs_1gpu"] = {g: s["amdahl_projection_seconds"][1] / v for g, v in s["amdahl_projection_seconds"].items()}
+        s["lines"] = [
+            f"replicate timeline: wall {wall:.1f} s = parent prologue {s['parent_prologue_seconds']:.1f} s + dispatch loop "
+            f"{s['dispatch_loop_seconds']:.1f} s; {self.n} worker(s) on {self.n_g} GPU(s), start-up "
+            f"{s['worker_startup_seconds_mean']:.1f} s each (first one ready {first_ready:.1f} s after program start)",
+            f"  {len(recs)} units: {work:.1f} s of worker time (host slices + filters {host:.1f} s on loader threads), "
+            f"serial part {serial:.1f} s = {100 * s['serial_fraction']:.0f} % of the wall",
+            "  Amdahl projection at this serial part, same workers per GPU: " +
+            ", ".join(f"{g} GPU {v:.1f} s ({s['amdahl_speedup_vs_1gpu'][g]:.2f}x)" for g, v in s["amdahl_projection_seconds"].items())]
+        return s
+
+
+def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print, fits_per_gpu=1, poll_s=1.0,
+              host_prepare=None, unit_timeout=0.0):
+    """Run every unit once; returns the result records in unit order (ReplicatePool started, run and closed here).
+
+    units         list of dicts (small per-unit data; window units carry their window, not their genotypes)
+    shared        dict of data common to all units; NumPy arrays of >= 1 MB are placed in shared memory once and
+                  attached by every worker (the 0.5 GB bootstrap matrix is not pickled 16 times)"""
+    pool = ReplicatePool(args, fit_fn, n_gpus=n_gpus, fits_per_gpu=fits_per_gpu, prepare=prepare,
+                         host_prepare=host_prepare, log=log, poll_s=poll_s, unit_timeout=unit_timeout,
+                         max_workers=len(units))
+    try:
+        return pool.run(units, shared)
     finally:
-        for shm in handles:
-            shm.close()
-            shm.unlink()
-    return out
+        pool.close()
 
 
 def run_units_distributed(units, args, fit_fn, shared=None, prepare=None, device=None):
