@@ -56,8 +56,9 @@ typedef struct loc_dims {
     int Kp;    /* K rounded up to a multiple of 32            */
     int H;     /* --width                                     (locator.py:320)                    */
     int Hp;    /* H rounded up to a multiple of 32 (<= 512)   */
-    int L;     /* --nlayers: number of Dense+ELU layers, >= 2 (locator.py:319-323)                */
-    int n_pre; /* floor(L/2): ELU layers before Dropout       (locator.py:319)                    */
+    int L;     /* --nlayers: number of Dense+ELU layers, >= 1 (locator.py:319-323)                */
+    int n_pre; /* floor(L/2): ELU layers before Dropout       (locator.py:319); 0 for --nlayers 1:
+                  Dropout then acts on the BatchNorm output and its keep mask is [rows][Kp]        */
 } loc_dims;
 
 /* Offsets (in floats) of every tensor inside the flat parameter buffer.
@@ -208,6 +209,11 @@ int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const float* bet
 int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
                    const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
                    float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream);
+/* The same with Dropout directly on the BatchNorm output (--nlayers 1: floor(1/2) = 0 Dense layers precede the Dropout
+ * layer, locator.py:319-323): in_mask = keep flags [32][Kp], xhat -> xhat * mask * keep_scale before the contraction. */
+int loc_l1_forward_in_dropout(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                              const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
+                              float* a1, const uint8_t* in_mask, float keep_scale, void* stream);
 /* Large-M inference form of the same layer (model.predict / the validation pass of model.fit,
  * locator.py:414, :441, :367-376): a1[m][h] for n rows (any n >= 1; a1 must hold ceil(n/128)*128 rows) on
  * the bf16 matrix pipe.  Each fp32 weight (times the BatchNorm scale of its SNP) is split on chip into
@@ -264,6 +270,16 @@ int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows,
                          int alpha_tab_len, const float* lr, const int* t_base, int t_off, int grid,
                          const float* bn_next_stats, float* bn4_out, void* ev_after_main, const loc_tuning* tune,
                          void* stream);
+
+/* loc_l1_backward_adam for --nlayers 1 (Dropout on the BatchNorm output, see loc_l1_forward_in_dropout): dW1 uses
+ * xhat * mask * keep_scale and the gradient reaching gamma / beta is dxhat * mask * keep_scale.  n_b <= 32. */
+int loc_l1_backward_adam_in_dropout(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                                    const float* bn4, const float* dz1, float* w1s, float* m1s, float* v1s,
+                                    float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta,
+                                    float* v_beta, float* b1, float* m_b1, float* v_b1, float* gb_scratch,
+                                    const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
+                                    int t_off, int grid, const float* bn_next_stats, float* bn4_out,
+                                    const loc_tuning* tune, const uint8_t* in_mask, float keep_scale, void* stream);
 
 /* The main kernel of loc_l1_backward_adam alone (W1, b1 and the gamma/beta partial sums in gb_scratch); the
  * caller runs the gamma/beta update itself -- loc_train_step folds it into loc_stack_dw_adam_tail. */
@@ -331,7 +347,8 @@ int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int
 /* One minibatch step: BN stats -> forward -> loss -> backward -> Adam, on rows[0..n_b).
  * n_b <= 32, or <= LOC_MAX_BATCH when net->slot_rows = LOC_BATCH_SLOT (--batch_size > 32: needs the fused-stack
  * widths 64/128/256, epoch-level BN statistics for steps of more than 32 rows, and Dropout not directly after layer 1).
- * mask: keep flags for this step, [rows][Hp] with rows = 32*ceil(n_b/32) (NULL iff drop_p == 0).  loss_out: 1 float.
+ * mask: keep flags for this step, [rows][Hp] with rows = 32*ceil(n_b/32) - [32][Kp] when L == 1 (Dropout on the
+ * BatchNorm output) - (NULL iff drop_p == 0).  loss_out: 1 float.
  * bn_ready != 0: this step's [scale|shift|mean|rstd] is already in the workspace (loc_bn_epoch_stats or the
  * previous step's bn_next_stats) and the per-step statistics kernel is skipped.
  * bn_next_stats: [mean|var] of the next minibatch or NULL (see loc_l1_backward_adam).

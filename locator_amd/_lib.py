@@ -69,6 +69,11 @@ SIGNATURES = {
     "loc_bn_infer_scale_shift": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "loc_l1_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                  C.c_float, vp]),
+    "loc_l1_forward_in_dropout": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int, vp, vp,
+                                            C.c_float, vp]),
+    "loc_l1_backward_adam_in_dropout": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
+                                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
+                                                  vp, vp, C.POINTER(Tuning), vp, C.c_float, vp]),
     "loc_l1_rows_supported": (C.c_int, [C.c_int, C.c_int]),
     "loc_l1_forward_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, C.c_int64, vp,
                                       C.c_int, C.c_int, C.POINTER(Tuning), vp]),

@@ -19,8 +19,8 @@ extern "C" const char* loc_last_error(void) { return g_err; }
 extern "C" int loc_version(void) { return 1; }
 
 extern "C" int loc_make_dims(int K, int H, int L, loc_dims* out) {
-    if (K < 1 || H < 1 || H > 512 || L < 2) {
-        loc_set_error("loc_make_dims: need K >= 1, 1 <= width <= 512, nlayers >= 2 (got K=%d H=%d L=%d)", K, H, L);
+    if (K < 1 || H < 1 || H > 512 || L < 1) {
+        loc_set_error("loc_make_dims: need K >= 1, 1 <= width <= 512, nlayers >= 1 (got K=%d H=%d L=%d)", K, H, L);
         return -1;
     }
     out->K = K;
@@ -122,7 +122,10 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     const float* at = net->alpha_tab;
     const int atl = net->alpha_tab_len;
 
-    const bool fused = net->wht && loc_stack_fused_supported(Hp);
+    // --nlayers 1: no hidden Dense layer, and the Dropout layer sits directly on the BatchNorm output (floor(1/2) = 0
+    // Dense layers before it, locator.py:319-323): the keep mask is [rows][Kp] and goes into the layer-1 kernels
+    const bool in_drop = use_drop && npre == 0;
+    const bool fused = L >= 2 && net->wht && loc_stack_fused_supported(Hp);
     if (slot > LOC_ROWS) {
         // --batch_size > 32: the step is linear in the rows (BatchNorm is the first layer, so its batch statistics
         // depend on the data only), hence the same kernels with two 32-row blocks per weight tile
@@ -143,6 +146,9 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         // large-M forward, exact fp32 products (3 bf16 pieces); fills one whole 128-row activation slot
         TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                                 w.partial_floats, act(1), 3, 0, &net->tune, stream));
+    } else if (in_drop) {
+        TRY(loc_l1_forward_in_dropout(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
+                                      net->l1_fwd_grid, act(1), mask, ks, stream));
     } else {
         const bool dr = use_drop && npre == 1;
         TRY(loc_l1_forward(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
@@ -193,10 +199,20 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                                t_off, stream));
     }
     // dW/Adam for layer 2
-    TRY(loc_dense_backward(nullptr, nullptr, nullptr, nullptr, ks, nullptr, in_of(2), dzl(2), P + lay.wh,
-                           M + lay.wh, V + lay.wh, P + lay.bh, M + lay.bh, V + lay.bh, Hp, at, atl, net->lr,
-                           net->t_base, t_off, stream));
+    if (L >= 2)
+        TRY(loc_dense_backward(nullptr, nullptr, nullptr, nullptr, ks, nullptr, in_of(2), dzl(2), P + lay.wh,
+                               M + lay.wh, V + lay.wh, P + lay.bh, M + lay.bh, V + lay.bh, Hp, at, atl, net->lr,
+                               net->t_base, t_off, stream));
     if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
+    if (in_drop) {
+        TRY(loc_l1_backward_adam_in_dropout(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
+                                            V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma,
+                                            M + lay.beta, V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at,
+                                            atl, net->lr, net->t_base, t_off, net->l1_bwd_grid, bn_next_stats, w.bn4,
+                                            &net->tune, mask, ks, stream));
+        if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+        return 0;
+    }
     TRY(loc_l1_backward_adam(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1, V + lay.w1,
                              P + lay.gamma, P + lay.beta, M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta,
                              P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
@@ -258,6 +274,15 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
             else
                 TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows + c0, nc, d, w.bn4, P + lay.w1, P + lay.b1,
                                         w.partial, w.partial_floats, w.a1_rows, pieces, 0, &net->tune, stream));
+            if (L == 1) {                 // no hidden layer: Dense(2), Dense(2) straight on a1, 32 rows per launch
+                for (int i = 0; i < nc; i += LOC_ROWS) {
+                    const int nb = nc - i < LOC_ROWS ? nc - i : LOC_ROWS;
+                    TRY(loc_head_eval(w.a1_rows + (int64_t)i * Hp, Hp, nb, P + lay.wa, P + lay.ba, P + lay.wb, P + lay.bb,
+                                      yhat + 2 * (int64_t)(c0 + i), with_targets ? rows + c0 + i : nullptr,
+                                      with_targets ? net->Y : nullptr, with_targets ? dist + c0 + i : nullptr, stream));
+                }
+                continue;
+            }
             TRY(loc_stack_forward_eval(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
                                        P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
                                        with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,
@@ -265,7 +290,7 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         }
         return 0;
     }
-    if (loc_stack_fused_supported(Hp)) {
+    if (L >= 2 && loc_stack_fused_supported(Hp)) {
         // layer 1 per 32-row block into consecutive scratch slots (the L activation slots hold 32*L rows),
         // then ONE row-parallel stack launch for the whole chunk
         const int chunk = LOC_ROWS * L;

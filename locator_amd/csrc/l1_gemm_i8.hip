@@ -194,6 +194,22 @@ __device__ __forceinline__ void barrier_i8() {
 // fragments later: a fragment F = c FP + j is requested right after F - NB is consumed and the head of iteration c'
 // sits just before fragment c' FP, so the heads counted are those with F - NB < c' FP <= F:  ceil((NB - j) / FP)
 constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1) / FP : 0; }
+// The same with the DMAs issued in bursts of BZ pairs every BZ-th iteration (iterations whose position u in the
+// unrolled body is a multiple of BZ; the body length is a multiple of BZ): genotype REQUESTS younger than fragment j of
+// the iteration at position u = 2 BZ per burst iteration i iterations back with i FP < NB - j
+constexpr int g8_dma_younger(int u, int j, int FP, int NB, int BZ) {
+    int n = 0;
+    for (int i = 0; i * FP < NB - j; ++i)
+        if (((u - i) % BZ + BZ) % BZ == 0) n += 2 * BZ;
+    return n;
+}
+// vmcnt before the rendezvous of the iteration at position u: its pair + 1 came with the burst i0 = LA - 1 + r
+// iterations ago (r = its place in that burst); younger are i0 whole iterations of FP fragment requests, the 2 D of
+// steps 0 and 1, the later bursts and the later pairs of the same burst
+constexpr int g8_dma_wait(int u, int D, int FP, int LA, int BZ) {
+    const int r = ((u + 1 - LA) % BZ + BZ) % BZ, i0 = LA - 1 + r;
+    return i0 * FP + 2 * D + 2 * BZ * (i0 / BZ) + 2 * (BZ - 1 - r);
+}
 
 // Timing ablations (never in the product build: `make ablate A=<bits>` writes ../liblocator_hip_ablate<bits>.so, results
 // are wrong by construction): 1 no fragment requests in the loop, 2 no genotype requests / stores, 4 no rendezvous,
@@ -207,10 +223,13 @@ constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1
 #ifndef G8_NB
 #define G8_NB 12      /* digit fragments in flight per wave (48 registers): 1.5 pairs at two planes, 3 at one      */
 #endif
-#define G8_RP 4       /* pairs in the genotype ring (4 x 16 KB) >= G8_LA + 2                                       */
+#define G8_RP 8       /* pairs in the genotype ring (8 x 16 KB) >= G8_LA + G8_BZ + 1                               */
 
 #ifndef G8_LA
 #define G8_LA 2       /* pairs between a genotype DMA and the iteration that reads it (measured: 2 beats 1, 3, 4)  */
+#endif
+#ifndef G8_BZ
+#define G8_BZ 1       /* genotype DMAs are issued for G8_BZ pairs at once, every G8_BZ-th iteration                */
 #endif
 #ifndef G8_DMA_MOD
 #define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1", ...)                              */
@@ -259,7 +278,7 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
     constexpr int FP = 4 * D;                               // fragments per pair
     // pairs per unrolled body, so that the ring slot of every fragment is static: the smallest UP with UP FP % NB == 0
     constexpr int UP = (FP % G8_NB == 0) ? 1 : ((2 * FP) % G8_NB == 0) ? 2 : ((3 * FP) % G8_NB == 0) ? 3 : 4;
-    static_assert((UP * FP) % G8_NB == 0 && G8_RP >= G8_LA + 2, "ring / unroll shapes");
+    static_assert((UP * FP) % G8_NB == 0 && G8_RP >= G8_LA + G8_BZ + 1 && UP % G8_BZ == 0, "ring / unroll shapes");
     const uint32_t lds0 = lds_addr32_i8(c.As);
     auto dma_x = [&](int pc, int i) {
         int cc = pc < c.cntp ? pc : c.cntp - 1;
@@ -302,13 +321,15 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
 
     // vmcnt before the rendezvous of iteration pc: this wave's DMA of pair pc + 1 was issued LA - 1 heads ago; younger are
     // the (LA - 1) later heads' 2 requests each, (LA - 1) whole iterations of FP fragment requests and the 2 D of steps 0, 1
-    constexpr int N_DMA = 2 * (G8_LA - 1) + (G8_LA - 1) * FP + 2 * D;
     auto pair = [&](int pc0, auto uc) {
         constexpr int u = decltype(uc)::value;             // position inside the unrolled body: ring slots are static
         const int pc = pc0 + u;
-        if (!(LOC_GEMM_ABLATE & 2)) {
-            dma_x(pc + G8_LA, 0);
-            dma_x(pc + G8_LA, 1);
+        if (!(LOC_GEMM_ABLATE & 2) && u % G8_BZ == 0) {
+#pragma unroll
+            for (int b = 0; b < G8_BZ; ++b) {
+                dma_x(pc + G8_LA + b, 0);
+                dma_x(pc + G8_LA + b, 1);
+            }
         }
         const uint32_t so = (pc % G8_RP) * (2 * G8_AIMG), so1 = ((pc + 1) % G8_RP) * (2 * G8_AIMG);
         // the pairs the fragments requested in this iteration belong to: NB fragments ahead
@@ -317,7 +338,7 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if (st == 2 && !(LOC_GEMM_ABLATE & 4)) {
-                { G8_T0(); wait_vm_i8<N_DMA>(); G8_T1(1); } // my rows of pair pc + 1 are in the ring
+                { G8_T0(); wait_vm_i8<g8_dma_wait(u, D, FP, G8_LA, G8_BZ)>(); G8_T1(1); }   // my rows of pair pc + 1 are in the ring
                 { G8_T0(); barrier_i8(); G8_T1(2); }        // ... and so are everyone's; nobody still reads pair pc - 1
             } else {
                 G8_T0(); wait_lgkm0_i8(); G8_T1(3);         // A[st & 1] has landed
@@ -330,12 +351,19 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
                 const int j = st * D + p;                   // fragment of the pair; static after unrolling
                 const int slot = (u * FP + j) % G8_NB;
                 G8_T0();
-                if (g8_heads(j, FP, G8_NB) == 1) wait_vm_i8<G8_NB - 1 + 2>();
-                else if (g8_heads(j, FP, G8_NB) == 2) wait_vm_i8<G8_NB - 1 + 4>();
-                else if (g8_heads(j, FP, G8_NB) == 3) wait_vm_i8<G8_NB - 1 + 6>();
-                else if (g8_heads(j, FP, G8_NB) == 4) wait_vm_i8<G8_NB - 1 + 8>();
-                else if (g8_heads(j, FP, G8_NB) == 5) wait_vm_i8<G8_NB - 1 + 10>();
-                else wait_vm_i8<G8_NB - 1>();
+                // static after unrolling: the if-chain stands in for a template argument that depends on the loop variables
+                {
+                    const int y = g8_dma_younger(u, j, FP, G8_NB, G8_BZ);
+                    if (y == 0) wait_vm_i8<G8_NB - 1>();
+                    else if (y == 2) wait_vm_i8<G8_NB - 1 + 2>();
+                    else if (y == 4) wait_vm_i8<G8_NB - 1 + 4>();
+                    else if (y == 6) wait_vm_i8<G8_NB - 1 + 6>();
+                    else if (y == 8) wait_vm_i8<G8_NB - 1 + 8>();
+                    else if (y == 10) wait_vm_i8<G8_NB - 1 + 10>();
+                    else if (y == 12) wait_vm_i8<G8_NB - 1 + 12>();
+                    else if (y == 16) wait_vm_i8<G8_NB - 1 + 16>();
+                    else wait_vm_i8<0>();
+                }
                 G8_T1(0);
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)

@@ -153,7 +153,10 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
                                                              const int32_t* __restrict__ rows, int n_b, int Kp,
                                                              const float* __restrict__ ss4,
                                                              const float* __restrict__ w1s,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             const uint8_t* __restrict__ in_mask, float in_ks) {
+    // in_mask != NULL: Dropout sits directly on the BatchNorm output (--nlayers 1, locator.py:319-323): keep flags
+    // [32][Kp], xhat -> xhat * mask * in_ks before the contraction
     constexpr int Hp = NHT * 32;
     constexpr int WF4 = NHT * 256;               // float4 per weight tile
     constexpr int NLD = (WF4 + 511) / 512;       // float4 loads per thread per tile
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
     const int64_t xrow = xvalid ? (int64_t)rows[xb] * pitch : 0;
 
     f32x4 wreg[NLD];
-    uint32_t xreg = 0;
+    uint32_t xreg = 0, mreg = 0x01010101u;
     f32x4 screg = {0, 0, 0, 0}, shreg = {0, 0, 0, 0};
 
     auto load_regs = [&](int kt) {
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
             xreg = *reinterpret_cast<const uint32_t*>(X + xrow + k0);
             screg = *reinterpret_cast<const f32x4*>(scale + k0);
             shreg = *reinterpret_cast<const f32x4*>(shift + k0);
+            if (in_mask) mreg = *reinterpret_cast<const uint32_t*>(in_mask + (int64_t)xb * Kp + k0);
         }
     };
     auto store_lds = [&](float* buf) {
@@ -211,6 +215,10 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
                 v[1] = fmaf((float)((xreg >> 8) & 255u), screg[1], shreg[1]);
                 v[2] = fmaf((float)((xreg >> 16) & 255u), screg[2], shreg[2]);
                 v[3] = fmaf((float)(xreg >> 24), screg[3], shreg[3]);
+                if (in_mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((mreg >> (8 * e)) & 255u) ? v[e] * in_ks : 0.f;
+                }
             }
             *reinterpret_cast<f32x4*>(xh + xb * LP + 4 * xq) = v;
         }
@@ -339,13 +347,16 @@ __device__ __forceinline__ void adam_update_fast(float& w, float& m, float& v, f
     w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
 }
 
-template <int NHT, int NTM = 13>
+template <int NHT, int NTM = 13, bool INDROP = false>
 __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
     const float* __restrict__ bn4, const float* __restrict__ dz1, float* __restrict__ w1s, float* __restrict__ m1s,
     float* __restrict__ v1s, float* __restrict__ gbs, float* __restrict__ b1, float* __restrict__ m_b1,
     float* __restrict__ v_b1, const float* __restrict__ alpha_tab, int alpha_tab_len,
-    const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
+    const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active,
+    const uint8_t* __restrict__ in_mask, float in_ks) {
+    // INDROP: Dropout directly on the BatchNorm output (--nlayers 1): keep flags in_mask [32][Kp].  The layer's input is
+    // xhat * mk (mk = mask * in_ks), so dW uses xhat * mk and the gradient reaching BatchNorm is dxhat * mk.
     constexpr int Hp = NHT * 32;
     constexpr int PZ = Hp + 1;  // dZ pitch: lanes<->rows reads hit distinct banks
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
     const float* rs_p = bn4 + 3 * (int64_t)Kp;
 
     float xh[16], xn[16];
+    float mk[INDROP ? 16 : 1];
     f32x16 dx = {0};
     int cur_kt = -1, first_ht = 0;
 
@@ -395,8 +407,9 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
         float pg = 0.f, pb = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pg = fmaf(dx[r], xn[r], pg);
-            pb += dx[r];
+            pg = fmaf(dx[r], xn[r], pg);            // INDROP: xn already carries mk
+            if (INDROP) pb = fmaf(dx[r], mk[r], pb);
+            else pb += dx[r];
         }
         pg += __shfl_xor(pg, 32);
         pb += __shfl_xor(pb, 32);
@@ -436,6 +449,11 @@ __global__ __launch_bounds__(256, 2) void l1_bwd_adam_kernel(
                 bool ok = b < n_b;
                 xh[r] = ok ? fmaf(xv, sc, sh) : 0.f;
                 xn[r] = ok ? (xv - mu) * rs : 0.f;
+                if (INDROP) {
+                    mk[r] = (ok && in_mask[(int64_t)b * Kp + k]) ? in_ks : 0.f;
+                    xh[r] *= mk[r];
+                    xn[r] *= mk[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx[r] = 0.f;
@@ -772,9 +790,10 @@ extern "C" int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const
     return 0;
 }
 
-extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
-                              const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
-                              float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream) {
+static int l1_forward_impl(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                           const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
+                           float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, const uint8_t* in_mask,
+                           float in_ks, void* stream) {
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_forward: n_b=%d out of 1..32", n_b); return -1; }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
     if (grid < 1) grid = 1;
@@ -785,7 +804,7 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
     {                                                                                                      \
         LOC_ENSURE_LDS((l1_fwd_partial_kernel<N>), lds);                                                   \
         hipLaunchKernelGGL(l1_fwd_partial_kernel<N>, dim3(grid), dim3(512), lds, (hipStream_t)stream, X,   \
-                           x_pitch, rows, n_b, d->Kp, scale_shift, w1s, partial);                          \
+                           x_pitch, rows, n_b, d->Kp, scale_shift, w1s, partial, in_mask, in_ks);          \
     }
     NHT_SWITCH(nht, LAUNCH_FWD)
 #undef LAUNCH_FWD
@@ -794,6 +813,20 @@ extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* 
                        32, d->Hp, b1, a1, a1_drop, mask, keep_scale);
     LOC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int loc_l1_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const loc_dims* d,
+                              const float* scale_shift, const float* w1s, const float* b1, float* partial, int grid,
+                              float* a1, float* a1_drop, const uint8_t* mask, float keep_scale, void* stream) {
+    return l1_forward_impl(X, x_pitch, rows, n_b, d, scale_shift, w1s, b1, partial, grid, a1, a1_drop, mask, keep_scale,
+                           nullptr, 1.f, stream);
+}
+extern "C" int loc_l1_forward_in_dropout(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                         const loc_dims* d, const float* scale_shift, const float* w1s, const float* b1,
+                                         float* partial, int grid, float* a1, const uint8_t* in_mask, float keep_scale,
+                                         void* stream) {
+    return l1_forward_impl(X, x_pitch, rows, n_b, d, scale_shift, w1s, b1, partial, grid, a1, nullptr, nullptr, 1.f,
+                           in_mask, keep_scale, stream);
 }
 
 // reduction of the large-M forward (l1_rows.hip): rows_p rows, no dropout
@@ -805,12 +838,16 @@ int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const 
 }
 
 // main kernel only (W1 / b1); the gamma/beta update that consumes gb_scratch is launched by the caller
-extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
-                                         const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
-                                         float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
-                                         float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
-                                         const float* lr, const int* t_base, int t_off, int grid,
-                                         const loc_tuning* tune, void* stream) {
+static int l1_backward_main_impl(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                 const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
+                                 float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
+                                 float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
+                                 const float* lr, const int* t_base, int t_off, int grid,
+                                 const loc_tuning* tune, const uint8_t* in_mask, float in_ks, void* stream) {
+    if (in_mask && n_b > LOC_ROWS) {
+        loc_set_error("loc_l1_backward_adam: dropout on the BatchNorm output (--nlayers 1) needs --batch_size <= 32");
+        return -1;
+    }
     if (n_b < 1 || n_b > LOC_MAX_BATCH) {
         loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..%d", n_b, LOC_MAX_BATCH);
         return -1;
@@ -825,7 +862,7 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
     const size_t lds = rb == 1 ? ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float)
                                : ((size_t)d->Hp * (32 * rb + 4) + d->Hp + 32 * rb) * sizeof(float);
     // tune->l1b_rows = 1: the bf16x3 row-block kernel also for <= 32 rows (measurement / parity switch)
-    if (rb == 1 && tune && tune->l1b_rows == 1 && nht == 8) {
+    if (rb == 1 && tune && tune->l1b_rows == 1 && nht == 8 && !in_mask) {
         const size_t lds = ((size_t)d->Hp * 36 + d->Hp + 32) * sizeof(float);
         LOC_ENSURE_LDS((l1_bwd_adam_rows_kernel<8, 13, 1>), lds);
         hipLaunchKernelGGL((l1_bwd_adam_rows_kernel<8, 13, 1>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X,
@@ -867,7 +904,19 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
         LOC_ENSURE_LDS((l1_bwd_adam_kernel<N>), lds);                                                          \
         hipLaunchKernelGGL(l1_bwd_adam_kernel<N>, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
-                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active, (const uint8_t*)nullptr, 1.f); \
+    }
+#define LAUNCH_BWD_DROP(N)                                                                                     \
+    {                                                                                                          \
+        LOC_ENSURE_LDS((l1_bwd_adam_kernel<N, 13, true>), lds);                                                \
+        hipLaunchKernelGGL((l1_bwd_adam_kernel<N, 13, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, \
+                           x_pitch, rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1, \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active, in_mask, in_ks);             \
+    }
+    if (in_mask) {
+        NHT_SWITCH(nht, LAUNCH_BWD_DROP)
+        LOC_CHECK_LAUNCH();
+        return 0;
     }
     // tune->l1b_nt_mask = 9 | 13 | 15 (or -1 for "nothing non-temporal") overrides the cache-policy mask NTM for
     // width 256 (measurement switch); 0 = the kernel's default
@@ -877,7 +926,7 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
         LOC_ENSURE_LDS((l1_bwd_adam_kernel<8, M>), lds);                                                       \
         hipLaunchKernelGGL((l1_bwd_adam_kernel<8, M>), dim3(grid), dim3(256), lds, (hipStream_t)stream, X, x_pitch, \
                            rows, n_b, d->K, d->Kp, bn4, dz1, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,        \
-                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);                             \
+                           alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active, (const uint8_t*)nullptr, 1.f); \
     }
     if (nht == 8 && ntm >= 0) {
         switch (ntm) {
@@ -888,8 +937,52 @@ extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, cons
         NHT_SWITCH(nht, LAUNCH_BWD)
     }
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD_DROP
     LOC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                         const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
+                                         float* m1s, float* v1s, float* b1, float* m_b1, float* v_b1,
+                                         float* gb_scratch, const float* alpha_tab, int alpha_tab_len,
+                                         const float* lr, const int* t_base, int t_off, int grid,
+                                         const loc_tuning* tune, void* stream) {
+    return l1_backward_main_impl(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, b1, m_b1, v_b1, gb_scratch, alpha_tab,
+                                 alpha_tab_len, lr, t_base, t_off, grid, tune, nullptr, 1.f, stream);
+}
+
+static int l1_backward_impl(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                            const loc_dims* d, const float* bn4, const float* dz1, float* w1s, float* m1s,
+                            float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
+                            float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
+                            float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
+                            const int* t_base, int t_off, int grid, const float* bn_next_stats,
+                            float* bn4_out, void* ev_after_main, const loc_tuning* tune, const uint8_t* in_mask,
+                            float in_ks, void* stream) {
+    int rc = l1_backward_main_impl(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, b1, m_b1, v_b1, gb_scratch,
+                                   alpha_tab, alpha_tab_len, lr, t_base, t_off, grid, tune, in_mask, in_ks, stream);
+    if (rc) return rc;
+    if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);
+    hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
+                       gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,
+                       t_base, t_off, d->Kp, bn_next_stats, bn4_out);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_l1_backward_adam_in_dropout(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                               const loc_dims* d, const float* bn4, const float* dz1, float* w1s,
+                                               float* m1s, float* v1s, float* gamma, float* beta, float* m_gamma,
+                                               float* v_gamma, float* m_beta, float* v_beta, float* b1, float* m_b1,
+                                               float* v_b1, float* gb_scratch, const float* alpha_tab,
+                                               int alpha_tab_len, const float* lr, const int* t_base, int t_off,
+                                               int grid, const float* bn_next_stats, float* bn4_out,
+                                               const loc_tuning* tune, const uint8_t* in_mask, float keep_scale,
+                                               void* stream) {
+    return l1_backward_impl(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, gamma, beta, m_gamma, v_gamma, m_beta,
+                            v_beta, b1, m_b1, v_b1, gb_scratch, alpha_tab, alpha_tab_len, lr, t_base, t_off, grid,
+                            bn_next_stats, bn4_out, nullptr, tune, in_mask, keep_scale, stream);
 }
 
 extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
@@ -899,13 +992,7 @@ extern "C" int loc_l1_backward_adam(const uint8_t* X, int64_t x_pitch, const int
                                     float* gb_scratch, const float* alpha_tab, int alpha_tab_len, const float* lr,
                                     const int* t_base, int t_off, int grid, const float* bn_next_stats,
                                     float* bn4_out, void* ev_after_main, const loc_tuning* tune, void* stream) {
-    int rc = loc_l1_backward_adam_main(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, b1, m_b1, v_b1, gb_scratch,
-                                       alpha_tab, alpha_tab_len, lr, t_base, t_off, grid, tune, stream);
-    if (rc) return rc;
-    if (ev_after_main) (void)hipEventRecord((hipEvent_t)ev_after_main, (hipStream_t)stream);
-    hipLaunchKernelGGL(l1_gamma_beta_adam_kernel, dim3((d->K + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->K,
-                       gb_scratch, gamma, beta, m_gamma, v_gamma, m_beta, v_beta, alpha_tab, alpha_tab_len, lr,
-                       t_base, t_off, d->Kp, bn_next_stats, bn4_out);
-    LOC_CHECK_LAUNCH();
-    return 0;
+    return l1_backward_impl(X, x_pitch, rows, n_b, d, bn4, dz1, w1s, m1s, v1s, gamma, beta, m_gamma, v_gamma, m_beta,
+                            v_beta, b1, m_b1, v_b1, gb_scratch, alpha_tab, alpha_tab_len, lr, t_base, t_off, grid,
+                            bn_next_stats, bn4_out, ev_after_main, tune, nullptr, 1.f, stream);
 }

@@ -17,7 +17,7 @@ Deliberate, documented deviations:
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 128 rows (the reference default is 32; 33..128 needs a --width that pads to 64,
-    128 or 256 and --nlayers >= 4 with dropout), --nlayers must be >= 2 and --width <= 512;
+    128 or 256 and --nlayers >= 4 with dropout) and --width to 512;
   * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """

@@ -83,7 +83,8 @@ class LocatorNet:
         self.t_base_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ws = torch.empty(self.lib.loc_workspace_floats(C.byref(self.d)), dtype=torch.float32, device=dev)
         # transposed hidden kernels for the fused backward chain (derived state, see refresh_transposed)
-        self.use_fused = bool(self.lib.loc_stack_fused_supported(self.d.Hp))
+        # --nlayers 1 has no hidden stack (and its Dropout acts on the BatchNorm output): per-layer kernels
+        self.use_fused = bool(self.lib.loc_stack_fused_supported(self.d.Hp)) and self.d.L >= 2
         self.wht = (torch.zeros((self.d.L - 1) * self.d.Hp * self.d.Hp, dtype=torch.float32, device=dev)
                     if self.use_fused else None)
         nkt = self.d.Kp // 32
@@ -99,6 +100,12 @@ class LocatorNet:
         self._net = None
         self.init_weights()
 
+    @property
+    def mask_width(self):
+        """Keep flags per row of one step's dropout mask: Hp, or Kp when the Dropout layer sits on the BatchNorm output
+        (--nlayers 1, locator.py:319-323)."""
+        return self.d.Kp if self.d.n_pre == 0 else self.d.Hp
+
     def params_changed(self):
         """Weights, gamma/beta or BatchNorm moving statistics are about to change: a kept many-row weight image is stale."""
         self._image_mode = 0
@@ -109,6 +116,8 @@ class LocatorNet:
         if not 1 <= batch_size <= LOC_MAX_BATCH:
             raise ValueError(f"--batch_size must be in 1..{LOC_MAX_BATCH} for the HIP path (got {batch_size})")
         if batch_size > LOC_ROWS:
+            if self.d.L < 2:
+                raise ValueError("--batch_size > 32 needs --nlayers >= 2")
             if not self.use_fused or self.d.Hp > 256:
                 raise ValueError("--batch_size > 32 needs a --width that pads to 64, 128 or 256 "
                                  "(33..64, 97..128 or 225..256)")
@@ -171,7 +180,7 @@ class LocatorNet:
 
     def refresh_transposed(self):
         """WhT[l] = Wh[l]^T; needed whenever the hidden kernels are written by anything but the Adam kernel."""
-        if self.wht is not None:
+        if self.wht is not None and self.d.L >= 2:
             _lib.check(self.lib.loc_transpose_hidden(self.params.data_ptr() + 4 * self.lay.wh, self.wht.data_ptr(),
                                                      self.d.Hp, self.d.L - 1, _stream()), "loc_transpose_hidden")
 
@@ -256,7 +265,8 @@ class LocatorNet:
     # ------------------------------------------------------------------ ops
     def train_step(self, rows, n_b, t_off, mask, loss_out, ev0=None, ev1=None, bn_ready=False, bn_next=None):
         """One minibatch step on X[rows[:n_b]].  rows: int32 device tensor (>= n_b entries),
-        mask: uint8 device tensor [32*Hp] of keep flags or None, loss_out: 1-element float32 view.
+        mask: uint8 device tensor [32*Hp] of keep flags ([32*Kp] when nlayers == 1: mask_width) or None, loss_out:
+        1-element float32 view.
         bn_ready / bn_next: epoch-level BN statistics (see epoch_bn_stats)."""
         self.params_changed()
         net = self._net or self.cnet()

@@ -76,8 +76,8 @@ class EpochRunner:
         self.val_rows = torch.as_tensor(np.asarray(val_rows, dtype=np.int32)).to(dev)
         self.perm_host = torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory()
         self.perm_dev = torch.zeros(self.steps * self.batch, dtype=torch.int32, device=dev)
-        Hp = net.d.Hp
-        self.mask_stride = self.slot_rows * Hp
+        # keep flags per step: [rows][Hp], or [32][Kp] when the Dropout layer sits on the BatchNorm output (--nlayers 1)
+        self.mask_stride = self.slot_rows * net.mask_width
         self.masks = (torch.zeros(self.steps * self.mask_stride, dtype=torch.uint8, device=dev)
                       if net.drop_p > 0 else None)
         self.stats = torch.zeros(self.steps + max(self.n_val, 1), dtype=torch.float32, device=dev)

@@ -141,6 +141,9 @@ def forward(p, x, training, drop_mask=None, drop_p=0.25, update_moving=True):
     training   True: batch statistics + dropout; False: moving statistics
     drop_mask  (n, width) array of {0,1} keep flags (training only).  Keras draws
                it from its own unseeded RNG, so the oracle takes it as an input.
+               With nlayers == 1 the Dropout layer follows the BatchNormalization
+               directly (locator.py:319-323: floor(1/2) = 0 Dense layers before it),
+               so the mask is (n, K) and acts on the normalised genotypes.
     Returns (yhat (n,2), cache).  In training mode p's moving stats are updated
     in place (the forward pass owns that update in Keras)."""
     dt = p["gamma"].dtype
@@ -163,6 +166,9 @@ def forward(p, x, training, drop_mask=None, drop_p=0.25, update_moving=True):
     acts_in = []        # input to each dense layer
     acts_out = []       # ELU output of each hidden layer (pre-dropout)
     a = xh
+    if npre == 0 and training and drop_p > 0:
+        assert drop_mask is not None and drop_mask.shape == xh.shape
+        a = a * (drop_mask.astype(dt) * dt.type(1.0 / (1.0 - drop_p)))
     for l in range(nl):
         acts_in.append(a)
         z = a @ p["W"][l] + p["b"][l]
@@ -217,6 +223,8 @@ def loss_and_grads(p, x, y, drop_mask=None, drop_p=0.25, update_moving=True):
         g["W"][l] = c["acts_in"][l].T @ dz
         g["b"][l] = dz.sum(0)
         da = dz @ p["W"][l].T
+    if npre == 0 and drop_p > 0:                  # Dropout sits on the BatchNorm output (nlayers == 1)
+        da = da * (c["drop_mask"].astype(dt) * dt.type(1.0 / (1.0 - drop_p)))
     # da is now d loss / d x̂  (B x K); BN gamma/beta only (input is data)
     g["gamma"] = (da * c["xn"]).sum(0)
     g["beta"] = da.sum(0)
@@ -317,7 +325,7 @@ def fit(p, traingen, trainlocs, testgen, testlocs, *, batch_size=32, max_epochs=
     """model.fit with the three callbacks, then reload of the best weights.
 
     perm_fn(epoch) -> permutation of range(n_train)   (Keras: unseeded shuffle)
-    mask_fn(epoch, step, n_b) -> (n_b, width) keep mask (Keras: unseeded dropout)
+    mask_fn(epoch, step, n_b) -> (n_b, width) keep mask (Keras: unseeded dropout); (n_b, K) when nlayers == 1
     Returns (history dict, best_params).  ``p`` is left at the last epoch's weights."""
     n = traingen.shape[0]
     width = p["W"][0].shape[1]
@@ -325,7 +333,8 @@ def fit(p, traingen, trainlocs, testgen, testlocs, *, batch_size=32, max_epochs=
     if perm_fn is None:
         perm_fn = lambda e: rng.permutation(n)
     if mask_fn is None:
-        mask_fn = lambda e, s, nb: (rng.random((nb, width)) >= drop_p)
+        mask_w = width if n_pre(len(p["W"]) - 2) > 0 else p["W"][0].shape[0]
+        mask_fn = lambda e, s, nb: (rng.random((nb, mask_w)) >= drop_p)
     m = zeros_like_trainable(p) if m is None else m
     v = zeros_like_trainable(p) if v is None else v
     cb = Callbacks(patience, lr0)

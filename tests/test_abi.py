@@ -59,10 +59,12 @@ def test_dims_and_layout():
     assert lay.wh == lay.b1 + 256 and lay.bh == lay.wh + 9 * 256 * 256
     assert lay.n_trainable % 4 == 0 and lay.mov_var == lay.mov_mean + 5856
     assert lay.n_total == lay.mov_var + 5856
+    d1 = _lib.make_dims(10, 256, 1)         # --nlayers 1: no Dense layer before the Dropout layer
+    assert (d1.L, d1.n_pre) == (1, 0) and _lib.param_layout(d1).wh == _lib.param_layout(d1).bh
     d2 = _lib.make_dims(33, 100, 3)
     assert (d2.Kp, d2.Hp, d2.n_pre) == (64, 128, 1)
     with pytest.raises(_lib.LocatorHipError):
-        _lib.make_dims(10, 256, 1)          # nlayers < 2 unsupported (documented deviation)
+        _lib.make_dims(10, 256, 0)          # nlayers < 1
     with pytest.raises(_lib.LocatorHipError):
         _lib.make_dims(10, 1024, 4)
 

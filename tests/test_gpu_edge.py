@@ -57,6 +57,49 @@ def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     assert not flat[lay.b1 + d.H:lay.b1 + d.Hp].any() and not flat[lay.gamma + d.K:lay.gamma + d.Kp].any()
 
 
+@pytest.mark.parametrize("K,width,batch,n_train,drop_p", [
+    (300, 64, 32, 100, 0.25),      # last batch of 4
+    (5830, 256, 32, 90, 0.25),     # the fixture's SNP count at the default width; last batch of 26
+    (97, 33, 7, 30, 0.5),          # K = 3 tiles + 1 SNP, width padded 33 -> 64, batch 7
+    (200, 256, 32, 64, 0.0),       # no dropout at all
+])
+def test_single_hidden_layer_puts_dropout_on_the_batchnorm_output(K, width, batch, n_train, drop_p):
+    """--nlayers 1 (accepted by the reference, locator.py:77, :319-323): floor(1/2) = 0 Dense layers come before the
+    Dropout layer, so it masks the BatchNorm output (a K-wide mask per row), then Dense(width, elu), Dense(2), Dense(2).
+    3 epochs of fit vs oracle.fit with the same init, permutations and the DEVICE's masks; then predict."""
+    from locator_amd.train import EpochRunner
+    n_val = 9
+    x, y, p, rng = make_problem(n_train + n_val, K, width, 1, seed=K + width)
+    assert len(p["W"]) == 3
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + n_val)
+    net = build_net(x, y, p, drop_p=drop_p, seed=5)
+    assert net.d.L == 1 and net.d.n_pre == 0 and net.mask_width == net.d.Kp and not net.use_fused
+    runner = EpochRunner(net, tr, va, batch, use_graph=True)
+    perms = [np.random.default_rng(e).permutation(n_train) for e in range(3)]
+    masks, hist = [], {"loss": [], "val_loss": []}
+    for e in range(3):
+        l, vl = runner.run_epoch(perms[e])
+        if drop_p > 0:
+            masks.append(runner.masks.cpu().numpy().reshape(runner.steps, 32, net.d.Kp).copy())
+            assert 0.8 * (1 - drop_p) < masks[-1][:, :, :K].mean() < 1.2 * (1 - drop_p)
+        hist["loss"].append(l)
+        hist["val_loss"].append(vl)
+    pref = O.copy_params(p)
+    href, _ = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=batch, max_epochs=3, patience=100, drop_p=drop_p,
+                    perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s, :nb, :K])
+    assert maxerr(hist["loss"], href["loss"]) < 5e-4, (hist["loss"], href["loss"])
+    assert maxerr(hist["val_loss"], href["val_loss"]) < 5e-4
+    errs = params_err(net.export_params(), pref)
+    assert max(errs.values()) < 1e-4, errs
+    n = x.shape[0]
+    for rows_n in (n, min(n, 35)):                           # more than 32 rows (large-M layer 1 + heads per 32) and a remainder
+        r = torch.arange(rows_n, dtype=torch.int32, device="cuda")
+        yhat = torch.zeros((rows_n, 2), device="cuda")
+        net.predict_rows(r, rows_n, yhat)
+        torch.cuda.synchronize()
+        assert maxerr(yhat.cpu().numpy(), O.predict(pref, x[:rows_n])) < 2e-4
+
+
 def test_no_dropout_and_dropout_on_first_layer():
     """--dropout_prop 0 (no mask anywhere) and nlayers 2/3 (Dropout directly after the layer-1 Dense)."""
     for nlayers, drop_p in [(2, 0.5), (3, 0.25), (4, 0.0)]:
@@ -117,7 +160,8 @@ def test_unsupported_configurations_are_rejected_with_messages():
     X = upload_genotypes(x)
     Y = torch.zeros((8, 2), device="cuda")
     with pytest.raises(_lib.LocatorHipError, match="nlayers"):
-        LocatorNet(X, Y, 40, 64, 1)
+        LocatorNet(X, Y, 40, 64, 0)
+    LocatorNet(X, Y, 40, 64, 1)                                        # --nlayers 1 is accepted (round 3)
     with pytest.raises(_lib.LocatorHipError, match="width"):
         LocatorNet(X, Y, 40, 600, 4)
     # --batch_size: 1..128; above 32 only on the fused-stack widths up to 256 and with Dropout after layer >= 2
@@ -134,6 +178,8 @@ def test_unsupported_configurations_are_rejected_with_messages():
     with pytest.raises(ValueError, match="nlayers"):
         EpochRunner(LocatorNet(X, Y, 40, 64, 3, 0.25), tr, va, 40)
     EpochRunner(LocatorNet(X, Y, 40, 64, 3, 0.0), tr, va, 40)          # no dropout: any depth >= 2 is fine
+    with pytest.raises(ValueError, match="nlayers"):
+        EpochRunner(LocatorNet(X, Y, 40, 64, 1, 0.0), tr, va, 40)      # more than 32 rows per step need a hidden stack
 
 
 def _two_epochs(tuning):

@@ -55,6 +55,8 @@ def _torch_loss(p, x, y, mask, drop_p):
     var = ((xt - mu) ** 2).mean(0)
     a = (xt - mu) / torch.sqrt(var + O.BN_EPS) * tp["gamma"] + tp["beta"]
     nl = len(p["W"]) - 2
+    if O.n_pre(nl) == 0 and drop_p > 0:           # --nlayers 1: Dropout directly after the BatchNormalization
+        a = a * torch.tensor(mask.astype(np.float64)) / (1 - drop_p)
     for l in range(nl):
         a = torch.nn.functional.elu(a @ tp["W"][l] + tp["b"][l])
         if l == O.n_pre(nl) - 1 and drop_p > 0:
@@ -67,7 +69,8 @@ def _torch_loss(p, x, y, mask, drop_p):
 
 
 @pytest.mark.parametrize("n,K,width,nlayers,drop_p", [
-    (16, 64, 32, 10, 0.25), (7, 40, 16, 4, 0.5), (32, 128, 64, 3, 0.0), (5, 33, 8, 2, 0.25)])
+    (16, 64, 32, 10, 0.25), (7, 40, 16, 4, 0.5), (32, 128, 64, 3, 0.0), (5, 33, 8, 2, 0.25), (9, 48, 16, 1, 0.25),
+    (6, 20, 8, 1, 0.0)])
 def test_gradients_match_torch_autograd(n, K, width, nlayers, drop_p):
     rng = np.random.default_rng(7)
     p = O.init_params(K, width, nlayers, rng)
@@ -77,7 +80,7 @@ def test_gradients_match_torch_autograd(n, K, width, nlayers, drop_p):
         p["b"][l] = rng.normal(0, 0.1, p["b"][l].shape)
     x = rng.integers(0, 3, (n, K)).astype(np.uint8)
     y = rng.normal(0, 1, (n, 2))
-    mask = (rng.random((n, width)) >= drop_p).astype(np.uint8)
+    mask = (rng.random((n, width if O.n_pre(nlayers) > 0 else K)) >= drop_p).astype(np.uint8)
     loss, g, yhat = O.loss_and_grads(O.copy_params(p), x, y, mask, drop_p)
     tl, tp, ty = _torch_loss(p, x, y, mask, drop_p)
     assert abs(loss - tl) < 1e-12
