@@ -6,9 +6,10 @@
 #   gpurun_out/<tag>_bench_replicates2.json      python3 bench.py --replicates-per-gpu 2
 #   gpurun_out/<tag>_bench_2ranks_selflaunch.json  python3 bench.py --gpus 2 --device-index 0 --dist-backend gloo (no launcher)
 #   gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
-#   gpurun_out/<tag>_gemm_pmc.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters and kernel times
+#   gpurun_out/<tag>_gemm_pmc_1000.json, _4096.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters (with the effective
+#                                                 clock from GRBM_GUI_ACTIVE) and kernel times, int8 and bf16 kernels
 # Copy what should be judged into profiles/ (tracked).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -25,10 +26,12 @@ cd /tmp
 rm -rf $O/prof_kt
 rocprofv3 --kernel-trace --stats -d $O/prof_kt -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2> $O/prof_kt.err
 cp $O/prof_kt/k_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
-bash $R/tools/gemm_pmc.sh > $O/gemm_pmc.log 2>&1
-cp $O/gemm_pmc.json $O/${TAG}_gemm_pmc.json
+bash $R/tools/gemm_pmc.sh 1000 > $O/gemm_pmc.log 2>&1
+bash $R/tools/gemm_pmc.sh 4096 >> $O/gemm_pmc.log 2>&1
+cp $O/gemm_pmc_1000.json $O/${TAG}_gemm_pmc_1000.json
+cp $O/gemm_pmc_4096.json $O/${TAG}_gemm_pmc_4096.json
 rm -rf $O/gemm_kt
-rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000,4096 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
 cp $O/gemm_kt/k_kernel_stats.csv $O/${TAG}_gemm_kernel_stats.csv
 tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
