@@ -22,16 +22,19 @@
 //                        digit plane), laid out [16-SNP chunk c][unit n][16 SNPs]: a wave's MFMA B operand for one
 //                        32-SNP step is two contiguous 512-byte runs.  Plane 0 is the most significant digit.  Also
 //                        the shift term's per-block partial sums (shared with l1_gemm.hip's cvec reduction).
-//   l1_gemm_i8_kernel    workgroup = 8 waves on a 128-row x 256-unit tile, split over SNP groups exactly like
-//                        l1_gemm_kernel: a wave owns 32 units and ALL 128 rows, its digit fragments go HBM/L2 -> VGPRs
-//                        (a ring of 6 tiles = 3 blocks ahead), only the raw genotype block is shared through a 4-slot
-//                        LDS ring (8 KB per block, XOR-placed so that the 8-lane store groups and the 16-lane read
-//                        groups are bank-conflict free).  The two waves of each SIMD run half a block apart between
-//                        two barriers per block: one issues the block's 8 MFMAs per digit from registers while its
-//                        partner reads the next block's 8 A fragments, stores its 16 genotype bytes and requests.
-//                        There is NO vector-ALU work in the loop.  Two digits accumulate side by side (2 x 64
-//                        accumulator registers); the exact mode folds them into fp32 and walks the K range a second
-//                        time for the least significant plane (genotypes re-read from L2, 8 MFMAs per block).
+//   l1_gemm_i8_kernel    workgroup = 8 waves on a 128-row x 256-unit tile; the SNP range is split over groups, group g
+//                        owning a CONTIGUOUS run of pairs of 64-SNP blocks.  A wave owns 32 units and ALL 128 rows: its
+//                        digit fragments go HBM/L2 -> VGPRs (12 fragments = 1.5 pairs in flight, saddr-form requests),
+//                        only the raw genotype rows are shared: LDS-DMA into a ring of pairs, [row][128 B] with the
+//                        eight 16-byte pieces of a row XOR-placed so that the lane-linear DMA and the 16-lane read
+//                        groups are bank-conflict free.  All eight waves run one software-pipelined stream and meet
+//                        once per pair (g8_sweep below); there is NO vector-ALU work in the loop.  Two digits
+//                        accumulate side by side (2 x 64 accumulator registers); the exact mode stores their fp32
+//                        fold and walks the K range a second time for the least significant plane (genotypes then
+//                        L2-hot, 8 MFMAs per block), adding it in place.
+//                        History (git log): the first version was l1_gemm_kernel's half-block
+//                        ping-pong with the widening removed - 215 us at 4096 rows x 2 digits, the same cycle count as
+//                        bf16 x 1; this schedule with scalar-base requests 203, DMA lookahead 2 pairs 194.
 //   reduction            l1_gemm_reduce_kernel of l1_gemm.hip (fixed-order sum of the group partials + shift + b1, ELU).
 #include "common.h"
 #include <type_traits>
@@ -266,7 +269,7 @@ __device__ __forceinline__ void dma16_i8(const void* gsrc, uint32_t lds_dst) {
 // iteration the wave starts the DMA of its 16 rows of the pair G8_LA iterations ahead (two requests of 8 rows x 128
 // bytes; ring of G8_RP pairs x 16 KB, row m at m*128 with its eight 16-byte pieces XOR-placed by (m >> 1) & 7, which
 // keeps both the lane-linear DMA stores and the 16-lane read groups on distinct banks) - no register, no LDS store
-// instruction, and four pairs of slack against HBM latency.  Each 32-SNP step then waits for the A fragments it
+// instruction, and two pairs of slack against HBM latency (G8_LA, measured: 2 beats 1, 3, 4).  Each 32-SNP step then waits for the A fragments it
 // prefetched one step earlier, prefetches the next step's four fragments (16 registers, double buffered) and issues
 // D x 4 MFMAs, one fragment request after every 4 (saddr form: the pair base is a scalar, the lane part and the
 // in-pair constant sit in FP VGPRs - no address arithmetic in the loop).  The rendezvous sits in the middle of the
