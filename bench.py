@@ -204,7 +204,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                 run = lambda: _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n_rows,
                                                                     C.byref(d), image.data_ptr(), digits, 2,
                                                                     P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
-                                                                    a1.data_ptr(), 0, st()))
+                                                                    a1.data_ptr(), 0, None, st()))
                 key = "int8x%d" % digits
                 out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
                 out[key]["tolerance"] = PREDICT_MODE_INFO[key]

@@ -92,6 +92,9 @@ typedef struct loc_tuning {
                              -1 = none; 0 = default (13: moments and the W1 write-back)                             */
     int l1b_rows;         /* 1: route <= 32-row steps of width 256 through the bf16x3 row-block backward           */
     int rows_rt;          /* 8: 256-row tiles in loc_l1_forward_rows (width 256, even number of 128-row tiles)     */
+    int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
+                             fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
+                             0 = default                                                                            */
 } loc_tuning;
 
 /* Everything a training / inference step needs.  All device pointers. */
@@ -254,7 +257,7 @@ int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const flo
                           void* stream);
 int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                            const void* image, int digits, int x_max, const float* b1, float* partial,
-                           int64_t partial_floats, float* a1, int target_blocks, void* stream);
+                           int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats

@@ -40,7 +40,7 @@ class Layout(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("stack_helpers", C.c_int), ("stack_xcd_stride", C.c_int), ("l1b_nt_mask", C.c_int),
-                ("l1b_rows", C.c_int), ("rows_rt", C.c_int)]
+                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int)]
 
 
 class Net(C.Structure):
@@ -86,7 +86,7 @@ SIGNATURES = {
     "loc_l1_image_i8_bytes": (C.c_int64, [C.POINTER(Dims), C.c_int]),
     "loc_l1_image_i8_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_l1_forward_gemm_i8": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp, vp,
-                                         C.c_int64, vp, C.c_int, vp]),
+                                         C.c_int64, vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_genotype_max": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     "loc_l1_backward_adam_main": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(Tuning), vp]),

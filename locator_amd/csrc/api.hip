@@ -267,7 +267,7 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
             if (i8)
                 TRY(loc_l1_forward_gemm_i8(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, digits, net->x_max,
-                                           P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, stream));
+                                           P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, &net->tune, stream));
             else if (gemm)
                 TRY(loc_l1_forward_gemm(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, pieces, P + lay.b1,
                                         w.partial, w.partial_floats, w.a1_rows, 0, stream));

@@ -163,13 +163,28 @@ __device__ __forceinline__ void rd4(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& 
 // Global loads as asm with hand-counted s_waitcnt vmcnt: the compiler's own bookkeeping merges the prologue's and the
 // loop's in-flight state at the loop header and then waits for almost everything in the first blocks of every
 // unrolled body (seen as vmcnt(2) where 9 loads may stay in flight).  The counts are in the loop below.
+// COUNT TABLE (per wave, requests in program order; P = pieces, 4 fragments per (block, piece) tile):
+//   load phase of a block      1 genotype request (load_x)
+//   matrix phase of a block    P tiles x 4 fragment requests (load_b_part), each issued right after the 4 MFMAs that
+//                              consumed the fragment it replaces, three tiles (12 requests) ahead
+//   wait before widening       the bytes were requested two blocks ago: younger are 2 x 4P fragment requests and one
+//                              genotype request                                               -> vmcnt(8P + 1)
+//   wait before a fragment     requested three tiles ago: 11 younger fragment requests plus one genotype request per
+//                              block boundary crossed on the way (P = 1: three, P = 2: two for piece 0 and one for
+//                              piece 1, P = 3: one)                                           -> vmcnt(14 | 13 | 12)
+// Editing the request order in block() means re-deriving these; a -DLOC_GEMM_DEBUG_DRAIN build turns every count into
+// vmcnt(0) for parity debugging.
 template <typename T>
 __device__ __forceinline__ void gload16(T& r, const void* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+#ifdef LOC_GEMM_DEBUG_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 // LDS traffic of this wave done, then the workgroup barrier (no vmcnt wait: weight / genotype requests stay in flight)

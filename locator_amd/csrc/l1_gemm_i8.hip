@@ -48,8 +48,9 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 #define G8_HP 256
 #define G8_TILE (G8_HP * G8_BK)   /* 16384: one (SNP block, digit plane) tile, int8 */
 #define G8_AIMG (G8_BM * G8_BK)   /* 8192: raw genotype image of one SNP block     */
-#define G8_LDS 131072             /* 4 genotype images in the loop; the epilogue stages 8 x 16 KB of partials */
-#define G8_RING 6                 /* digit tiles in flight per wave (48 registers)  */
+#define G8_LDS 131072             /* 4 pairs of genotype rows (64 KB) in the loop; the epilogue stages 128 KB of partials */
+#define G8_WAVE_UNIT_TILES 1      /* default unit tiles per wave: 1 = 8 waves x 256 registers, 2 = 4 waves x 512 registers
+                                     (loc_tuning.gemm_i8_unit_tiles overrides) */
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -161,24 +162,22 @@ __device__ __forceinline__ void rd4_i8(i32x4& a0, i32x4& a1, i32x4& a2, i32x4& a
 }
 // Global loads as asm with hand-counted s_waitcnt vmcnt (see l1_gemm.hip: the compiler's own counts collapse at the
 // loop header).  COUNT TABLE, per wave, requests in program order.  One iteration = one PAIR of 64-SNP blocks =
-// 4 steps of 32 SNPs; FP = 4 D digit fragments per pair, consumed in the order (step, plane); NB = G8_NB fragments
-// in flight:
-//   head of an iteration   2 genotype requests (16 bytes per lane each: this thread's share of the pair after next)
+// 4 steps of 32 SNPs; a wave owns UT unit tiles (of 32 units); FP = 4 D UT digit fragments per pair, consumed in the
+// order (step, plane, unit tile); NB fragments in flight; DPW = 2 UT genotype DMAs per wave and pair:
+//   head of an iteration   DPW genotype DMAs (this wave's 16 UT rows of the pair G8_LA iterations ahead)
 //   after each 4 MFMAs     1 fragment request, NB fragments ahead of the one just consumed
 //   => fragment j of a pair (j = 0..FP-1) was requested NB fragments ago; younger than it are NB - 1 fragment requests
-//      and 2 genotype requests per iteration head crossed (g8_heads() below):     vmcnt(NB - 1 + 2 heads)
-//      (a LOC_GEMM_DEBUG_DRAIN build replaces every count by vmcnt(0) for parity debugging)
-//   => the genotype bytes stored at the head of an iteration were requested at the previous head; younger than them
-//      are that iteration's FP fragment requests:                                  vmcnt(FP)
-template <typename T>
-__device__ __forceinline__ void gload16_i8(T& r, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-}
+//      and the DMAs of every iteration head crossed (g8_heads() below):          vmcnt(NB - 1 + DPW heads)
+//   => before the rendezvous of an iteration (after steps 0 and 1) the wave's DMAs of the NEXT pair must have landed:
+//      they were issued LA - 1 heads ago; younger are (LA - 1) later heads' DMAs, (LA - 1) whole iterations of FP
+//      fragment requests and the FP / 2 of steps 0, 1:                 vmcnt((LA - 1)(DPW + FP) + FP / 2)
+//   (a LOC_GEMM_DEBUG_DRAIN build replaces every count by vmcnt(0) for parity debugging: make debug_drain)
 template <int N>
 __device__ __forceinline__ void wait_vm_i8() {
 #ifdef LOC_GEMM_DEBUG_DRAIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // parity-debug build: every count replaced by a full drain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -193,63 +192,28 @@ __device__ __forceinline__ void barrier_i8() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// iteration heads (2 genotype requests each) between the request of fragment j of a pair and its consumption NB
-// fragments later: a fragment F = c FP + j is requested right after F - NB is consumed and the head of iteration c'
-// sits just before fragment c' FP, so the heads counted are those with F - NB < c' FP <= F:  ceil((NB - j) / FP)
+// iteration heads between the request of fragment j of a pair and its consumption NB fragments later: a fragment
+// F = c FP + j is requested right after F - NB is consumed and the head of iteration c' sits just before fragment
+// c' FP, so the heads counted are those with F - NB < c' FP <= F:  ceil((NB - j) / FP)
 constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1) / FP : 0; }
-// The same with the DMAs issued in bursts of BZ pairs every BZ-th iteration (iterations whose position u in the
-// unrolled body is a multiple of BZ; the body length is a multiple of BZ): genotype REQUESTS younger than fragment j of
-// the iteration at position u = 2 BZ per burst iteration i iterations back with i FP < NB - j
-constexpr int g8_dma_younger(int u, int j, int FP, int NB, int BZ) {
-    int n = 0;
-    for (int i = 0; i * FP < NB - j; ++i)
-        if (((u - i) % BZ + BZ) % BZ == 0) n += 2 * BZ;
-    return n;
-}
-// vmcnt before the rendezvous of the iteration at position u: its pair + 1 came with the burst i0 = LA - 1 + r
-// iterations ago (r = its place in that burst); younger are i0 whole iterations of FP fragment requests, the 2 D of
-// steps 0 and 1, the later bursts and the later pairs of the same burst
-constexpr int g8_dma_wait(int u, int D, int FP, int LA, int BZ) {
-    const int r = ((u + 1 - LA) % BZ + BZ) % BZ, i0 = LA - 1 + r;
-    return i0 * FP + 2 * D + 2 * BZ * (i0 / BZ) + 2 * (BZ - 1 - r);
-}
 
 // Timing ablations (never in the product build: `make ablate A=<bits>` writes ../liblocator_hip_ablate<bits>.so, results
-// are wrong by construction): 1 no fragment requests in the loop, 2 no genotype requests / stores, 4 no rendezvous,
-// 8 no A-fragment reads, 16 genotype DMA always from the group's first pair (L2-hot), 32 in-kernel stamps: every wave
-// adds up the shader cycles it spends in the fragment waits, the DMA wait, the rendezvous and the LDS waits and
-// leaves them (with its total) where its partial sums would go (tools/rows_gemm_bench.py --stamps).
+// are wrong by construction): 1 no fragment requests in the loop, 2 no genotype DMAs, 4 no rendezvous, 8 no A-fragment
+// reads, 16 genotype DMA always from the group's first pair (L2-hot).
 #ifndef LOC_GEMM_ABLATE
 #define LOC_GEMM_ABLATE 0
 #endif
-
-#ifndef G8_NB
-#define G8_NB 12      /* digit fragments in flight per wave (48 registers): 1.5 pairs at two planes, 3 at one      */
-#endif
-#define G8_RP 8       /* pairs in the genotype ring (8 x 16 KB) >= G8_LA + G8_BZ + 1                               */
-
 #ifndef G8_LA
 #define G8_LA 2       /* pairs between a genotype DMA and the iteration that reads it (measured: 2 beats 1, 3, 4)  */
 #endif
-#ifndef G8_BZ
-#define G8_BZ 1       /* genotype DMAs are issued for G8_BZ pairs at once, every G8_BZ-th iteration                */
-#endif
+#define G8_RP 4       /* pairs in the genotype ring (4 x 16 KB) >= G8_LA + 2                                       */
 #ifndef G8_DMA_MOD
-#define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1", ...)                              */
-#endif
-
-#if LOC_GEMM_ABLATE & 32
-#define G8_T0() const uint64_t t0__ = __builtin_amdgcn_s_memtime()
-#define G8_T1(slot) c.prof[slot] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0__)
-#else
-#define G8_T0()
-#define G8_T1(slot)
+#define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1": measured, within 2 %)            */
 #endif
 
 struct g8_ctx {
-    mutable uint32_t prof[6];     // stamps build: cycles in [fragment waits, DMA wait, rendezvous, LDS waits]
-    const uint8_t* xrow[2];       // this lane's two genotype rows (DMA role): rows 16 w + 8 i + (lane >> 3)
-    uint32_t xpiece[2];           // 16 x the piece of the pair's 128-byte line this lane fetches for each of them
+    const uint8_t* xrow[4];       // this lane's genotype rows (DMA role): rows 16 UT w + 8 i + (lane >> 3), i < 2 UT
+    uint32_t xpiece[4];           // 16 x the piece of the pair's 128-byte line this lane fetches for each of them
     const unsigned char* tiles;
     unsigned char* As;
     int p0, cntp, Kp, w, jl, hi, lane;   // this group's pairs of 64-SNP blocks: [p0, p0 + cntp)
@@ -264,40 +228,42 @@ __device__ __forceinline__ void dma16_i8(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// One walk over this workgroup's SNP blocks with D digit planes [plane0, plane0 + D) of the DT planes in the image.
-// All eight waves run the same software-pipelined stream and meet once per pair.  Genotypes: at the head of an
-// iteration the wave starts the DMA of its 16 rows of the pair G8_LA iterations ahead (two requests of 8 rows x 128
-// bytes; ring of G8_RP pairs x 16 KB, row m at m*128 with its eight 16-byte pieces XOR-placed by (m >> 1) & 7, which
-// keeps both the lane-linear DMA stores and the 16-lane read groups on distinct banks) - no register, no LDS store
-// instruction, and two pairs of slack against HBM latency (G8_LA, measured: 2 beats 1, 3, 4).  Each 32-SNP step then waits for the A fragments it
-// prefetched one step earlier, prefetches the next step's four fragments (16 registers, double buffered) and issues
-// D x 4 MFMAs, one fragment request after every 4 (saddr form: the pair base is a scalar, the lane part and the
-// in-pair constant sit in FP VGPRs - no address arithmetic in the loop).  The rendezvous sits in the middle of the
-// pair - before it the wave waits for its own share of the NEXT pair's DMA - so the first step of the next pair is
-// prefetched half a pair ahead of its use and nobody waits for an LDS round trip after it; the two waves of a SIMD
-// are NOT phase-locked: whichever has operands feeds the matrix pipe.
-template <int D, int DT>
-__device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&acc)[D][4]) {
-    constexpr int FP = 4 * D;                               // fragments per pair
+// One walk over this workgroup's SNP blocks with D digit planes [plane0, plane0 + D) of the DT planes in the image, by a
+// wave that owns UT unit tiles (UT = 1: eight waves per workgroup, two per SIMD, 256 registers each; UT = 2: four waves,
+// one per SIMD with the whole 512-register file - twice the accumulators and room for NB = 32 fragments in flight).
+// All waves run the same software-pipelined stream and meet once per pair.  Genotypes: at the head of an iteration
+// the wave starts the DMA of its rows of the pair G8_LA iterations ahead (8 rows x 128 bytes per request; ring of
+// G8_RP pairs x 16 KB, row m at m*128 with its eight 16-byte pieces XOR-placed by (m >> 1) & 7, which keeps both the
+// lane-linear DMA stores and the 16-lane read groups on distinct banks) - no register, no LDS store instruction.  Each
+// 32-SNP step then waits for the A fragments it prefetched one step earlier, prefetches the next step's four fragments
+// (16 registers, double buffered) and issues D x UT x 4 MFMAs, one fragment request after every 4 (saddr form: the pair
+// base is a scalar, the lane part and the in-pair constant sit in FP VGPRs - no address arithmetic in the loop).  The
+// rendezvous sits in the middle of the pair - before it the wave waits for its own share of the NEXT pair's DMA - so
+// the first step of the next pair is prefetched half a pair ahead of its use and nobody waits for an LDS round trip
+// after it; with two waves per SIMD they are NOT phase-locked: whichever has operands feeds the matrix pipe.
+template <int D, int DT, int UT, int NB>
+__device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&acc)[D][UT][4]) {
+    constexpr int FP = 4 * D * UT;                          // fragments per pair
+    constexpr int DPW = 2 * UT;                             // genotype DMAs per wave and pair
     // pairs per unrolled body, so that the ring slot of every fragment is static: the smallest UP with UP FP % NB == 0
-    constexpr int UP = (FP % G8_NB == 0) ? 1 : ((2 * FP) % G8_NB == 0) ? 2 : ((3 * FP) % G8_NB == 0) ? 3 : 4;
-    static_assert((UP * FP) % G8_NB == 0 && G8_RP >= G8_LA + G8_BZ + 1 && UP % G8_BZ == 0, "ring / unroll shapes");
+    constexpr int UP = (FP % NB == 0) ? 1 : ((2 * FP) % NB == 0) ? 2 : ((3 * FP) % NB == 0) ? 3 : 4;
+    static_assert((UP * FP) % NB == 0 && G8_RP >= G8_LA + 2, "ring / unroll shapes");
     const uint32_t lds0 = lds_addr32_i8(c.As);
     auto dma_x = [&](int pc, int i) {
         int cc = pc < c.cntp ? pc : c.cntp - 1;
         if (LOC_GEMM_ABLATE & 16) cc = 0;
         uint32_t koff = (uint32_t)(c.p0 + cc) * (2 * G8_BK) + c.xpiece[i];
         if (koff > (uint32_t)(c.Kp - 16)) koff = c.Kp - 16; // only in the zero-weight padding of the last pair
-        dma16_i8(c.xrow[i] + koff, lds0 + (pc % G8_RP) * (2 * G8_AIMG) + (16 * c.w + 8 * i) * 128);
+        dma16_i8(c.xrow[i] + koff, lds0 + (pc % G8_RP) * (2 * G8_AIMG) + (16 * UT * c.w + 8 * i) * 128);
     };
-    // Fragment j = step * D + p of a pair sits at  pair base + voff[j],  voff[j] = lane part + e DT TILE + kk 8192 + p TILE
-    // (step = 2 e + kk)
+    // Fragment j = (step * D + p) * UT + ut of a pair sits at  pair base + voff[j],
+    //   voff[j] = lane part (unit tile UT w + ut) + e DT TILE + kk 8192 + p TILE      (step = 2 e + kk)
     uint32_t voff[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
-        const int st = j / D, p = j - st * D;
-        voff[j] = (uint32_t)(c.hi * 4096 + (c.w * 32 + c.jl) * 16 + (st >> 1) * (DT * G8_TILE) + (st & 1) * 8192 +
-                             (plane0 + p) * G8_TILE);
+        const int ut = j % UT, sp = j / UT, st = sp / D, p = sp - st * D;
+        voff[j] = (uint32_t)(c.hi * 4096 + ((c.w * UT + ut) * 32 + c.jl) * 16 + (st >> 1) * (DT * G8_TILE) +
+                             (st & 1) * 8192 + (plane0 + p) * G8_TILE);
     }
     auto pair_base = [&](int pc) -> const unsigned char* { // pairs past the end re-read the last one (never used)
         const int cc = pc < c.cntp ? pc : c.cntp - 1;
@@ -312,69 +278,64 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
         aoff[st] = lds0 + c.jl * 128 + (((2 * st + c.hi) ^ ((c.jl >> 1) & 7)) << 4);
 
     // prologue: pairs 0..LA-1 and fragments 0..NB-1 requested, step 0 of pair 0 fetched
-    i32x4 B[G8_NB];
+    i32x4 B[NB];
     i32x4 A[2][4];
 #pragma unroll
-    for (int pc = 0; pc < G8_LA; ++pc) { dma_x(pc, 0); dma_x(pc, 1); }
+    for (int pc = 0; pc < G8_LA; ++pc)
 #pragma unroll
-    for (int f = 0; f < G8_NB; ++f) load_b(B[f], pair_base(f / FP), voff[f % FP]);
+        for (int i = 0; i < DPW; ++i) dma_x(pc, i);
+#pragma unroll
+    for (int f = 0; f < NB; ++f) load_b(B[f], pair_base(f / FP), voff[f % FP]);
     wait_vm_i8<0>();
     barrier_i8();
     rd4_i8(A[0][0], A[0][1], A[0][2], A[0][3], aoff[0]);
 
-    // vmcnt before the rendezvous of iteration pc: this wave's DMA of pair pc + 1 was issued LA - 1 heads ago; younger are
-    // the (LA - 1) later heads' 2 requests each, (LA - 1) whole iterations of FP fragment requests and the 2 D of steps 0, 1
+    constexpr int N_DMA = (G8_LA - 1) * (DPW + FP) + FP / 2;
     auto pair = [&](int pc0, auto uc) {
         constexpr int u = decltype(uc)::value;             // position inside the unrolled body: ring slots are static
         const int pc = pc0 + u;
-        if (!(LOC_GEMM_ABLATE & 2) && u % G8_BZ == 0) {
+        if (!(LOC_GEMM_ABLATE & 2)) {
 #pragma unroll
-            for (int b = 0; b < G8_BZ; ++b) {
-                dma_x(pc + G8_LA + b, 0);
-                dma_x(pc + G8_LA + b, 1);
-            }
+            for (int i = 0; i < DPW; ++i) dma_x(pc + G8_LA, i);
         }
         const uint32_t so = (pc % G8_RP) * (2 * G8_AIMG), so1 = ((pc + 1) % G8_RP) * (2 * G8_AIMG);
         // the pairs the fragments requested in this iteration belong to: NB fragments ahead
-        const unsigned char* const sb_lo = pair_base(pc + G8_NB / FP);
-        const unsigned char* const sb_hi = pair_base(pc + G8_NB / FP + 1);
+        const unsigned char* const sb_lo = pair_base(pc + NB / FP);
+        const unsigned char* const sb_hi = pair_base(pc + NB / FP + 1);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if (st == 2 && !(LOC_GEMM_ABLATE & 4)) {
-                { G8_T0(); wait_vm_i8<g8_dma_wait(u, D, FP, G8_LA, G8_BZ)>(); G8_T1(1); }   // my rows of pair pc + 1 are in the ring
-                { G8_T0(); barrier_i8(); G8_T1(2); }        // ... and so are everyone's; nobody still reads pair pc - 1
+                wait_vm_i8<N_DMA>();                        // my rows of pair pc + 1 are in the ring
+                barrier_i8();                               // ... and so are everyone's; nobody still reads pair pc - 1
             } else {
-                G8_T0(); wait_lgkm0_i8(); G8_T1(3);         // A[st & 1] has landed
+                wait_lgkm0_i8();                            // A[st & 1] has landed
             }
             if (LOC_GEMM_ABLATE & 8) {}
             else if (st < 3) rd4_i8(A[(st + 1) & 1][0], A[(st + 1) & 1][1], A[(st + 1) & 1][2], A[(st + 1) & 1][3], aoff[st + 1] + so);
             else rd4_i8(A[0][0], A[0][1], A[0][2], A[0][3], aoff[0] + so1);
 #pragma unroll
-            for (int p = 0; p < D; ++p) {
-                const int j = st * D + p;                   // fragment of the pair; static after unrolling
-                const int slot = (u * FP + j) % G8_NB;
-                G8_T0();
-                // static after unrolling: the if-chain stands in for a template argument that depends on the loop variables
-                {
-                    const int y = g8_dma_younger(u, j, FP, G8_NB, G8_BZ);
-                    if (y == 0) wait_vm_i8<G8_NB - 1>();
-                    else if (y == 2) wait_vm_i8<G8_NB - 1 + 2>();
-                    else if (y == 4) wait_vm_i8<G8_NB - 1 + 4>();
-                    else if (y == 6) wait_vm_i8<G8_NB - 1 + 6>();
-                    else if (y == 8) wait_vm_i8<G8_NB - 1 + 8>();
-                    else if (y == 10) wait_vm_i8<G8_NB - 1 + 10>();
-                    else if (y == 12) wait_vm_i8<G8_NB - 1 + 12>();
-                    else if (y == 16) wait_vm_i8<G8_NB - 1 + 16>();
-                    else wait_vm_i8<0>();
-                }
-                G8_T1(0);
+            for (int p = 0; p < D; ++p)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    acc[p][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[st & 1][tm], B[slot], acc[p][tm], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(LOC_GEMM_ABLATE & 1)) load_b(B[slot], (j + G8_NB % FP) < FP ? sb_lo : sb_hi, voff[(j + G8_NB) % FP]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int ut = 0; ut < UT; ++ut) {
+                    const int j = (st * D + p) * UT + ut;   // fragment of the pair; static after unrolling
+                    const int slot = (u * FP + j) % NB;
+                    // static after unrolling: the if-chain stands in for a template argument that depends on loop variables
+                    {
+                        const int h = g8_heads(j, FP, NB);
+                        if (h == 0) wait_vm_i8<NB - 1>();
+                        else if (h == 1) wait_vm_i8<NB - 1 + DPW>();
+                        else if (h == 2) wait_vm_i8<NB - 1 + 2 * DPW>();
+                        else if (h == 3) wait_vm_i8<NB - 1 + 3 * DPW>();
+                        else if (h == 4) wait_vm_i8<NB - 1 + 4 * DPW>();
+                        else wait_vm_i8<0>();
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+                        acc[p][ut][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[st & 1][tm], B[slot], acc[p][ut][tm], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(LOC_GEMM_ABLATE & 1)) load_b(B[slot], (j + NB % FP) < FP ? sb_lo : sb_hi, voff[(j + NB) % FP]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
     };
     int pc = 0;
@@ -393,24 +354,24 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
     wait_vm_i8<0>();
     wait_lgkm0_i8();
 #pragma unroll
-    for (int f = 0; f < G8_NB; ++f) asm volatile("" ::"v"(B[f]));
+    for (int f = 0; f < NB; ++f) asm volatile("" ::"v"(B[f]));
     asm volatile("" ::"v"(A[0][0]), "v"(A[0][1]), "v"(A[0][2]), "v"(A[0][3]));
     __syncthreads();                                        // the epilogue's staging images overlap the ring
 }
 
-template <int DT>
-__global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __restrict__ X, int64_t pitch,
-                                                            const int32_t* __restrict__ rows, int n, int Kp,
-                                                            const unsigned char* __restrict__ tiles,
-                                                            const float* __restrict__ delta,
-                                                            float* __restrict__ partial, int G, int n_mt, int npairs) {
+// UT = 1: 512 threads, a wave = 128 rows x 32 units, 12 fragments in flight; UT = 2: 256 threads, one wave per SIMD,
+// a wave = 128 rows x 64 units, 32 fragments in flight.
+template <int DT, int UT>
+__global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* __restrict__ X, int64_t pitch,
+                                                                 const int32_t* __restrict__ rows, int n, int Kp,
+                                                                 const unsigned char* __restrict__ tiles,
+                                                                 const float* __restrict__ delta,
+                                                                 float* __restrict__ partial, int G, int n_mt, int npairs) {
+    constexpr int NB = UT == 1 ? 12 : 32;
+    constexpr int WU = 32 * UT;                             // units per wave
     extern __shared__ __attribute__((aligned(1024))) unsigned char g8_smem[];
     const int t = threadIdx.x, lane = t & 63;
     g8_ctx c;
-#if LOC_GEMM_ABLATE & 32
-    for (int i = 0; i < 6; ++i) c.prof[i] = 0;
-    const uint64_t t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
-#endif
     c.w = __builtin_amdgcn_readfirstlane(t >> 6);
     c.lane = lane;
     c.jl = lane & 31;
@@ -434,8 +395,8 @@ __global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __rest
     c.tiles = tiles;
     c.As = g8_smem;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = 16 * c.w + 8 * i + (lane >> 3);      // row of the 128-row tile this lane moves
+    for (int i = 0; i < 2 * UT; ++i) {
+        const int m = 16 * UT * c.w + 8 * i + (lane >> 3);  // row of the 128-row tile this lane moves
         int r = mt * G8_BM + m;
         if (r > n - 1) r = n - 1;
         c.xrow[i] = X + (int64_t)rows[r] * pitch;
@@ -443,61 +404,55 @@ __global__ __launch_bounds__(G8_NT) void l1_gemm_i8_kernel(const uint8_t* __rest
     }
     const int Mp = n_mt * G8_BM;
 
-    i32x16 acc[2][4];
+    i32x16 acc[2][UT][4];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[p][tm] = i32x16{0};
-    g8_sweep<2, DT>(c, 0, acc);
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) acc[p][ut][tm] = i32x16{0};
+    g8_sweep<2, DT, UT, NB>(c, 0, acc);
 
-    // D[i = row][j = unit] x delta_j: wave tile 128 rows x 32 units through a wave-private LDS image, then 16-byte stores.
+    // D[i = row][j = unit] x delta_j: wave tile 128 rows x WU units through a wave-private LDS image, then 16-byte stores.
     // Three planes: the two leading ones go out first (65536 * plane 0 + 256 * plane 1, in units of delta), the K range
     // is walked again for the least significant plane, and the same thread adds it to what it stored - delta is a power
-    // of two, so the sum equals the one a 192-register accumulator set would have produced, without the spills that
-    // set costs at 256 registers per wave.
-    const float dl = delta[c.w * 32 + c.jl];
-    float* const ep = reinterpret_cast<float*>(g8_smem) + c.w * 4096;
-    float* const pout = partial + ((int64_t)g * Mp + mt * G8_BM) * G8_HP + c.w * 32;
-    auto emit = [&](const i32x16 (&hi_p)[4], const i32x16 (&lo_p)[4], float s_hi, float s_lo, bool add) {
+    // of two, so the sum equals the one a three-plane accumulator set would have produced, without the registers.
+    float dl[UT];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+    for (int ut = 0; ut < UT; ++ut) dl[ut] = delta[(c.w * UT + ut) * 32 + c.jl];
+    float* const ep = reinterpret_cast<float*>(g8_smem) + c.w * (G8_BM * WU);
+    float* const pout = partial + ((int64_t)g * Mp + mt * G8_BM) * G8_HP + c.w * WU;
+    auto emit = [&](const i32x16 (&hi_p)[UT][4], const i32x16 (&lo_p)[UT][4], float s_hi, float s_lo, bool add) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[(tm * 32 + rowmap(r, c.hi)) * 32 + c.jl] = (s_hi * (float)hi_p[tm][r] + s_lo * (float)lo_p[tm][r]) * dl;
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[(tm * 32 + rowmap(r, c.hi)) * WU + ut * 32 + c.jl] =
+                        (s_hi * (float)hi_p[ut][tm][r] + s_lo * (float)lo_p[ut][tm][r]) * dl[ut];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int LPR = WU / 4, RPI = 64 / LPR;        // lanes per row, rows per wave instruction
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = i * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 32 + c4);
+        for (int i = 0; i < G8_BM / RPI; ++i) {
+            const int row = i * RPI + lane / LPR, c4 = (lane % LPR) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * WU + c4);
             f32x4* dst = reinterpret_cast<f32x4*>(pout + (int64_t)row * G8_HP + c4);
             if (add) v = v + *dst;
             *dst = v;
         }
     };
-#if LOC_GEMM_ABLATE & 32
-    {
-        const uint64_t t_loop = __builtin_amdgcn_s_memtime();
-        emit(acc[0], acc[1], 256.f, 1.f, false);
-        __syncthreads();
-        const uint64_t t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            float* o = partial + ((int64_t)blockIdx.x * 8 + c.w) * 16;
-            o[0] = (float)(t_end - t_start); o[1] = (float)(t_loop - t_start); o[2] = (float)(r_end - r_start);
-            for (int i = 0; i < 4; ++i) o[3 + i] = (float)c.prof[i];
-            o[7] = 12345.f;
-        }
-        return;
-    }
-#endif
     if (DT == 2) {
         emit(acc[0], acc[1], 256.f, 1.f, false);
     } else {
         emit(acc[0], acc[1], 65536.f, 256.f, false);
         __syncthreads();                                    // the staging images overlap the genotype ring
-        i32x16 lo[1][4];
+        i32x16 lo[1][UT][4];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) lo[0][tm] = i32x16{0};
-        g8_sweep<1, DT>(c, 2, lo);
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) lo[0][ut][tm] = i32x16{0};
+        g8_sweep<1, DT, UT, NB>(c, 2, lo);
         emit(lo[0], lo[0], 1.f, 0.f, true);
     }
 }
@@ -550,7 +505,8 @@ extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift
 
 extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                                       const void* image, int digits, int x_max, const float* b1, float* partial,
-                                      int64_t partial_floats, float* a1, int target_blocks, void* stream) {
+                                      int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune,
+                                      void* stream) {
     if (n < 1) { loc_set_error("loc_l1_forward_gemm_i8: n=%d", n); return -1; }
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) {
         loc_set_error("loc_l1_forward_gemm_i8: width %d / %d digits unsupported", d->Hp, digits);
@@ -586,15 +542,20 @@ extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const i
     const float* delta = reinterpret_cast<const float*>(base + g8_delta_off());
     const unsigned char* tiles = base + g8_tiles_off(d);
     hipStream_t st = (hipStream_t)stream;
-    if (digits == 2) {
-        LOC_ENSURE_LDS((l1_gemm_i8_kernel<2>), G8_LDS);
-        hipLaunchKernelGGL(l1_gemm_i8_kernel<2>, dim3(n_mt * G), dim3(G8_NT), G8_LDS, st, X, x_pitch, rows, n, d->Kp,
-                           tiles, delta, partial, G, n_mt, nkt / 2);
-    } else {
-        LOC_ENSURE_LDS((l1_gemm_i8_kernel<3>), G8_LDS);
-        hipLaunchKernelGGL(l1_gemm_i8_kernel<3>, dim3(n_mt * G), dim3(G8_NT), G8_LDS, st, X, x_pitch, rows, n, d->Kp,
-                           tiles, delta, partial, G, n_mt, nkt / 2);
+#define G8_LAUNCH(DTV, UTV)                                                                                     \
+    {                                                                                                           \
+        LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, UTV>), G8_LDS);                                                  \
+        hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, UTV>), dim3(n_mt * G), dim3(G8_NT / UTV), G8_LDS, st, X, x_pitch, \
+                           rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);                            \
     }
+    const int ut = tune && (tune->gemm_i8_unit_tiles == 1 || tune->gemm_i8_unit_tiles == 2) ? tune->gemm_i8_unit_tiles
+                                                                                             : G8_WAVE_UNIT_TILES;
+    if (ut == 2) {
+        if (digits == 2) G8_LAUNCH(2, 2) else G8_LAUNCH(3, 2)
+    } else {
+        if (digits == 2) G8_LAUNCH(2, 1) else G8_LAUNCH(3, 1)
+    }
+#undef G8_LAUNCH
     LOC_CHECK_LAUNCH();
     return gm_launch_reduce(partial, G, (int64_t)Mp * G8_HP, cvec, b1, a1, stream);
 }

@@ -259,4 +259,20 @@ def test_config4_many_row_gemm_at_500k_snps():
     ref, z = _a1_reference(p, x[rows[check]])
     err = np.abs(a1[check, :WIDTH] - ref).max()
     assert err < 5e-5, err                                   # exact products, fp32 accumulation over 500k terms
+    # the int8 form of the same sweep (the default): 32 groups of 122-123 pairs, digit planes of 0.39 GB; the i32
+    # accumulators hold at most 2 * 128 * 15,744 per group
+    from tests.test_gpu_gemm_i8 import run_gemm_i8
+    for digits, bar in ((3, 5e-5), (2, 5e-3)):
+        a8 = run_gemm_i8(net, torch.from_numpy(rows).cuda(), n, digits)
+        err8 = np.abs(a8[check, :WIDTH] - ref).max()
+        assert err8 < bar, (digits, err8)
+    # ... and through loc_predict (image kept for the second call), against oracle.predict
+    r = torch.from_numpy(rows[:700].copy()).cuda()
+    yhat = torch.zeros((700, 2), device="cuda")
+    net.predict_rows(r, 700, yhat)
+    net.predict_rows(r, 700, yhat)
+    torch.cuda.synchronize()
+    assert net._image_mode == 13 and net._net.l1_image_ready == 13
+    sel = check[check < 700]
+    assert maxerr(yhat.cpu().numpy()[sel], O.predict(p, x[rows[sel]])) < 5e-5
 

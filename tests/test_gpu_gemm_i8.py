@@ -48,7 +48,7 @@ def build_image(net, digits):
     return image, bn4
 
 
-def run_gemm_i8(net, rows, n, digits, x_max=2, target_blocks=0, scratch_tiles=256, image=None):
+def run_gemm_i8(net, rows, n, digits, x_max=2, target_blocks=0, scratch_tiles=256, image=None, unit_tiles=0):
     from locator_amd import _lib
     d, lay, lib = net.d, net.lay, net.lib
     if image is None:
@@ -58,7 +58,8 @@ def run_gemm_i8(net, rows, n, digits, x_max=2, target_blocks=0, scratch_tiles=25
     a1 = torch.full((mp, d.Hp), float("nan"), device="cuda")
     _lib.check(lib.loc_l1_forward_gemm_i8(net.X.data_ptr(), net.X.stride(0), rows.data_ptr(), n, C.byref(d),
                                           image.data_ptr(), digits, x_max, net.params.data_ptr() + 4 * lay.b1,
-                                          partial.data_ptr(), partial.numel(), a1.data_ptr(), target_blocks, None),
+                                          partial.data_ptr(), partial.numel(), a1.data_ptr(), target_blocks,
+                                          C.byref(_lib.Tuning(gemm_i8_unit_tiles=unit_tiles)), None),
                "loc_l1_forward_gemm_i8")
     torch.cuda.synchronize()
     return a1.cpu().numpy()
@@ -105,9 +106,10 @@ def test_digit_image_is_the_rounded_fixed_point_weight_bit_for_bit(digits):
     assert maxerr(cvec[:width], shift @ p["W"][0]) < 2e-5
 
 
+@pytest.mark.parametrize("unit_tiles", [1, 2])
 @pytest.mark.parametrize("K,n", [(5830, 450), (64, 1), (97, 130), (4096, 129), (3000, 300), (8192, 1000),
                                  (100, 128), (32, 5), (20000, 257)])
-def test_three_digits_is_fp32_exact(K, n):
+def test_three_digits_is_fp32_exact(K, n, unit_tiles):
     """K not a multiple of 64 / 128 (zero tail of the image, a zero tile pads an odd block count), K < one block, row
     counts around the 128-row tile edge, more row tiles than SNP groups allow at 256 workgroups."""
     width = 256
@@ -115,7 +117,7 @@ def test_three_digits_is_fp32_exact(K, n):
     net = build_net(x, y, p)
     assert net.lib.loc_l1_gemm_i8_supported(net.d.Hp, 3)
     r = rng.permutation(x.shape[0])[:n].astype(np.int32)
-    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, 3)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, 3, unit_tiles=unit_tiles)
     ref, _ = _a1_reference(p, x[r])
     assert maxerr(a1[:n, :width], ref) < 2e-5, maxerr(a1[:n, :width], ref)
     assert np.isfinite(a1).all()
@@ -167,9 +169,11 @@ def test_deterministic_and_independent_of_the_group_split():
     assert maxerr(a[:n], d[:n]) < 1e-5
 
 
+@pytest.mark.parametrize("unit_tiles", [1, 2])
 @pytest.mark.parametrize("digits,target_blocks", [(2, 0), (3, 0), (2, 48), (3, 24), (2, 8), (3, 8)])
-def test_every_loop_shape(digits, target_blocks):
-    """The unrolled body holds 6 SNP blocks and a remainder of 2 or 4 follows; the number of SNP groups decides how
+def test_every_loop_shape(digits, target_blocks, unit_tiles):
+    """The unrolled body holds 3 pairs of SNP blocks (eight waves, 12 fragments in flight) or 2 / 4 pairs (four waves,
+    32 in flight: two planes / one plane) and a remainder follows; the number of SNP groups decides how
     many blocks a workgroup walks.  K = 20,000 is 313 blocks (odd: one zero tile pads the last pair); 1000 rows at the
     default 256 workgroups = 32 groups of 8-10 blocks; 48 -> 6 groups of 52-54, 24 -> 3 of 104-106, 8 -> 1 group of all
     314.  Every row and unit is compared with the fp64 forward."""
@@ -177,7 +181,7 @@ def test_every_loop_shape(digits, target_blocks):
     x, y, p, rng = make_problem(n, K, width, 2, seed=11 + digits)
     net = build_net(x, y, p)
     r = rng.permutation(n).astype(np.int32)
-    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, digits, target_blocks=target_blocks)
+    a1 = run_gemm_i8(net, torch.from_numpy(r).cuda(), n, digits, target_blocks=target_blocks, unit_tiles=unit_tiles)
     ref, z = _a1_reference(p, x[r])
     err = maxerr(a1[:n, :width], ref)
     assert err < {3: 3e-5, 2: 4e-3}[digits], err

@@ -32,8 +32,8 @@ def main():
     ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMMs (l1_gemm.hip, l1_gemm_i8.hip)")
     ap.add_argument("--i8-only", action="store_true", help="only the int8 GEMM (l1_gemm_i8.hip)")
     ap.add_argument("--lib", default=None, help="another build of liblocator_hip.so (timing ablations)")
-    ap.add_argument("--stamps", action="store_true",
-                    help="with a stamps build (make ablate A=32): decode the per-wave cycle counts left in the scratch")
+    ap.add_argument("--unit-tiles", type=int, default=0,
+                    help="int8 GEMM: loc_tuning.gemm_i8_unit_tiles (1 = eight waves per workgroup, 2 = four waves with 512 registers)")
     a = ap.parse_args()
     if a.lib:
         _lib.use_library(os.path.abspath(a.lib))
@@ -99,7 +99,7 @@ def main():
                     _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
                                                           image.data_ptr(), digits, 2, P + 4 * lay.b1,
                                                           partial.data_ptr(), partial.numel(), a1.data_ptr(), blocks,
-                                                          None))
+                                                          C.byref(_lib.Tuning(gemm_i8_unit_tiles=a.unit_tiles)), None))
                 t = {}
                 for name, fn in (("prep", prep), ("gemm", run)):
                     for _ in range(5):
@@ -112,20 +112,9 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
-                if a.stamps:
-                    st = partial[:256 * 8 * 16].view(256 * 8, 16).cpu().numpy()
-                    st = st[st[:, 7] == 12345.0]
-                    tot = st[:, 0].mean()
-                    print(json.dumps({"stamps": "mean over %d waves" % len(st), "digits": digits, "cycles_total": round(float(tot)),
-                                      "cycles_loop": round(float(st[:, 1].mean())), "clock_ghz": round(float((st[:, 0] / st[:, 2]).mean()) * 0.1, 3),
-                                      "frac_fragment_waits": round(float((st[:, 3] / st[:, 0]).mean()), 3),
-                                      "frac_dma_wait": round(float((st[:, 4] / st[:, 0]).mean()), 3),
-                                      "frac_rendezvous": round(float((st[:, 5] / st[:, 0]).mean()), 3),
-                                      "frac_lds_waits": round(float((st[:, 6] / st[:, 0]).mean()), 3),
-                                      "max_wave_cycles": round(float(st[:, 0].max())), "min_wave_cycles": round(float(st[:, 0].min()))}))
                 flops = 2.0 * n * a.snps * a.width
                 rec = {"kernel": "int8 image+gemm", "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
-                       "digits": digits, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
+                       "digits": digits, "unit_tiles": a.unit_tiles, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
                        "tflops": round(flops / t["gemm"] * 1e-6, 1),
                        "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
                        "frac_bf16_peak_incl_prep": round(flops / (t["gemm"] + t["prep"]) * 1e-6 / BF16_PEAK_TFLOPS, 4),
