@@ -44,7 +44,9 @@ extern "C" {
 #endif
 
 #define LOC_ROWS 32 /* rows per row block = MFMA M                                              */
-#define LOC_MAX_BATCH 128 /* --batch_size limit: four 32-row blocks per step                        */
+#define LOC_MAX_BATCH 128 /* largest --batch_size of the row-block kernels: four 32-row blocks per step */
+#define LOC_BIG_BATCH_MAX 4096 /* --batch_size limit: above LOC_MAX_BATCH the step streams its row blocks from L2
+                                  (l1_bwd_adam_big_kernel, run-time block counts in the tail) - correct, not tuned */
 #define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
 #define LOC_PREDICT_CHUNK 4096 /* rows per large-M launch inside loc_predict: 4096, not 1024 (more rows per launch =
@@ -117,8 +119,9 @@ typedef struct loc_net {
     float* ws;
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
-    int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32), or
-                                LOC_BATCH_SLOT when --batch_size is 33..LOC_MAX_BATCH                    */
+    int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32),
+                                LOC_BATCH_SLOT when --batch_size is 33..LOC_MAX_BATCH, or --batch_size rounded up to a
+                                multiple of 128 above that (the workspace then comes from loc_workspace_floats_batch) */
     int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
                                 32-row fp32-MFMA kernel for every block of rows                          */
@@ -168,6 +171,8 @@ int loc_make_dims(int K, int H, int L, loc_dims* out);
 int loc_param_layout(const loc_dims* d, loc_layout* out);
 int64_t loc_w1s_index(int h, int k, int Hp);
 int64_t loc_workspace_floats(const loc_dims* d);
+/* the same for --batch_size up to `batch` rows (> LOC_MAX_BATCH: one activation slot holds ceil(batch / 128) * 128 rows) */
+int64_t loc_workspace_floats_batch(const loc_dims* d, int batch);
 
 /* ---- utility kernels ---- */
 /* Keras glorot_uniform init of one Dense kernel (locator.py:319-325 [K]): logical R x C (in x out),

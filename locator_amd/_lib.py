@@ -59,6 +59,7 @@ SIGNATURES = {
     "loc_param_layout": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout)]),
     "loc_w1s_index": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "loc_workspace_floats": (C.c_int64, [C.POINTER(Dims)]),
+    "loc_workspace_floats_batch": (C.c_int64, [C.POINTER(Dims), C.c_int]),
     "loc_init_glorot": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, vp]),
     "loc_init_uniform": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
     "loc_dropout_mask_fill": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),

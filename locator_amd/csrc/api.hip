@@ -68,11 +68,17 @@ static int64_t partial_floats_of(const loc_dims* d) {
 // The per-step scratch (activations, dz, head outputs) exists twice, selected by step parity (a step's tail
 // launch may still be reading its activations when a future overlapped schedule starts the next forward).  One activation slot holds `slot` rows (32, or
 // LOC_BATCH_SLOT when --batch_size > 32); the workspace is always sized for the larger one.
-static int slot_of(const loc_net* net) { return net->slot_rows > LOC_ROWS ? LOC_BATCH_SLOT : LOC_ROWS; }
+// (--batch_size > LOC_MAX_BATCH: the slot is the batch rounded up to 128 rows and the workspace comes from
+// loc_workspace_floats_batch.)
+static int slot_of(const loc_net* net) {
+    if (net->slot_rows > LOC_BATCH_SLOT) return (net->slot_rows + 127) / 128 * 128;
+    return net->slot_rows > LOC_ROWS ? LOC_BATCH_SLOT : LOC_ROWS;
+}
+static int slot_cap_of(const loc_net* net) { const int s = slot_of(net); return s > LOC_BATCH_SLOT ? s : LOC_BATCH_SLOT; }
 static int64_t per_step_floats(const loc_dims* d, int slot) {
     return (2 * (int64_t)d->L + 1) * slot * d->Hp + 8 * (int64_t)slot;
 }
-static ws_view carve(const loc_dims* d, float* ws, int parity = 0, int slot = LOC_ROWS) {
+static ws_view carve(const loc_dims* d, float* ws, int parity = 0, int slot = LOC_ROWS, int cap = LOC_BATCH_SLOT) {
     ws_view v;
     const int64_t blk = (int64_t)slot * d->Hp;
     const int64_t per_step = per_step_floats(d, slot);
@@ -84,13 +90,14 @@ static ws_view carve(const loc_dims* d, float* ws, int parity = 0, int slot = LO
     v.adrop = v.acts + d->L * blk;
     v.dz = v.adrop + blk;
     v.head_out = v.dz + d->L * blk;
-    v.a1_rows = v.partial + v.partial_floats + 2 * per_step_floats(d, LOC_BATCH_SLOT);
+    v.a1_rows = v.partial + v.partial_floats + 2 * per_step_floats(d, cap);
     return v;
 }
-extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
-    return 8 * (int64_t)d->Kp + partial_floats_of(d) + 2 * per_step_floats(d, LOC_BATCH_SLOT) +
-           (int64_t)LOC_PREDICT_CHUNK * d->Hp;
+extern "C" int64_t loc_workspace_floats_batch(const loc_dims* d, int batch) {
+    const int cap = batch > LOC_BATCH_SLOT ? (batch + 127) / 128 * 128 : LOC_BATCH_SLOT;
+    return 8 * (int64_t)d->Kp + partial_floats_of(d) + 2 * per_step_floats(d, cap) + (int64_t)LOC_PREDICT_CHUNK * d->Hp;
 }
+extern "C" int64_t loc_workspace_floats(const loc_dims* d) { return loc_workspace_floats_batch(d, LOC_BATCH_SLOT); }
 
 #define TRY(x)                 \
     do {                       \
@@ -99,13 +106,18 @@ extern "C" int64_t loc_workspace_floats(const loc_dims* d) {
     } while (0)
 
 extern "C" float* loc_workspace_bn4(const loc_net* net) { return carve(&net->d, net->ws).bn4; }
+// rows one --batch_size step may carry with this net's scratch
+static int max_rows_of(const loc_net* net) {
+    const int s = slot_of(net);
+    return s > LOC_BATCH_SLOT ? (s < LOC_BIG_BATCH_MAX ? s : LOC_BIG_BATCH_MAX) : (s > LOC_ROWS ? LOC_MAX_BATCH : LOC_ROWS);
+}
 
 extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
                               float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
                               void* ev_l1b1, void* stream) {
     const loc_dims* d = &net->d;
     const int slot = slot_of(net);
-    const int max_b = slot > LOC_ROWS ? LOC_MAX_BATCH : LOC_ROWS;
+    const int max_b = max_rows_of(net);
     if (n_b < 1 || n_b > max_b) { loc_set_error("loc_train_step: n_b=%d out of 1..%d", n_b, max_b); return -1; }
     const bool use_drop = net->drop_p > 0.f;
     if (use_drop && !mask) { loc_set_error("loc_train_step: dropout_prop > 0 needs a keep mask"); return -1; }
@@ -113,7 +125,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     loc_layout lay;
     loc_param_layout(d, &lay);
     float *P = net->params, *M = net->adam_m, *V = net->adam_v;
-    ws_view w = carve(d, net->ws, t_off & 1, slot);
+    ws_view w = carve(d, net->ws, t_off & 1, slot, slot_cap_of(net));
     const int Hp = d->Hp, L = d->L, npre = d->n_pre;
     const int64_t blk = (int64_t)slot * Hp, HH = (int64_t)Hp * Hp;
     auto act = [&](int l) { return w.acts + (l - 1) * blk; };        // ELU output of layer l (1-based)
@@ -143,7 +155,7 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
         TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
                                P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
     if (n_b > LOC_ROWS) {
-        // large-M forward, exact fp32 products (3 bf16 pieces); fills one whole 128-row activation slot
+        // large-M forward, exact fp32 products (3 bf16 pieces); fills whole 128-row tiles of the activation slot
         TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                                 w.partial_floats, act(1), 3, 0, &net->tune, stream));
     } else if (in_drop) {
@@ -245,7 +257,7 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     loc_layout lay;
     loc_param_layout(d, &lay);
     const float* P = net->params;
-    ws_view w = carve(d, net->ws);
+    ws_view w = carve(d, net->ws, 0, LOC_ROWS, slot_cap_of(net));
     const int Hp = d->Hp, L = d->L;
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,

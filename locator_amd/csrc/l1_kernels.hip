@@ -87,7 +87,8 @@ __global__ __launch_bounds__(128) void bn_epoch_stats_kernel(const uint8_t* __re
     for (int c = 0; c < 4; ++c) {
         if (k0 + c < K) {
             mu[c] = (float)s[c] / (float)n_b;
-            var[c] = (float)(n_b * ss[c] - s[c] * s[c]) / (float)(n_b * n_b);
+            // exact integer numerator; 64-bit, because n_b * ss reaches 2^31 from n_b = 182 rows of 255s on
+            var[c] = (float)((int64_t)n_b * ss[c] - (int64_t)s[c] * s[c]) / ((float)n_b * (float)n_b);
         }
     }
     float* o = stats_ep + (int64_t)step * 2 * Kp;
@@ -716,6 +717,140 @@ __global__ __launch_bounds__(RB > 2 ? 512 : 256, RB > 2 ? 1 : 2) void l1_bwd_ada
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer-1 backward + Adam for MORE than 128 rows (--batch_size 129..LOC_BIG_BATCH_MAX, accepted by the reference,
+// locator.py:122): the dz image of l1_bwd_adam_rows_kernel no longer fits the LDS, so this variant keeps its algebra
+// (S[h][k] = sum_b dz[b][h] (x[b][k] - c_k), dW and the gamma/beta sums derived from S and dzsum, dxhat never formed)
+// but streams dz from L2 row block by row block: per unit and 32-row block 16 fp32 MFMAs (v_mfma_f32_32x32x2_f32:
+// exact fp32 products) whose A operand is a coalesced 128-byte read of dz and whose B operand is x - c for the
+// block's rows.  It is matrix-bound (2 x n_b MFMA cycles per 12 KB of weight stream), not HBM-bound - a correct path
+// for a setting far from the default, not a tuned one.  dzsum comes from dz_colsum_kernel.  Same work partition, cache
+// policy, gamma/beta hand-off (gbs slots) and Adam arithmetic as the other two kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dz_colsum_kernel(const float* __restrict__ dz1, int n_rows, int Hp,
+                                                        float* __restrict__ dzsum) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= Hp) return;
+    float s = 0.f;
+    for (int b = 0; b < n_rows; ++b) s += dz1[(int64_t)b * Hp + h];      // fixed order
+    dzsum[h] = s;
+}
+
+template <int NHT, int NTM>
+__global__ __launch_bounds__(256, 2) void l1_bwd_adam_big_kernel(
+    const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b, int K, int Kp,
+    const float* __restrict__ bn4, const float* __restrict__ dz1, const float* __restrict__ dzsum_g,
+    float* __restrict__ w1s, float* __restrict__ m1s, float* __restrict__ v1s, float* __restrict__ gbs,
+    float* __restrict__ b1, float* __restrict__ m_b1, float* __restrict__ v_b1, const float* __restrict__ alpha_tab,
+    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, int n_active) {
+    constexpr int Hp = NHT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dzsum = smem;                                            // [Hp]
+    int* rows_l = reinterpret_cast<int*>(dzsum + Hp);               // [32 * nrb]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int jl = lane & 31, hi = lane >> 5;
+    const int nkt = Kp / KT;
+    const int nrb = (n_b + 31) / 32;                                // dz rows n_b..32*nrb-1 are zero (stack kernel)
+    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
+    for (int h = t; h < Hp; h += 256) dzsum[h] = dzsum_g[h];
+    for (int i = t; i < 32 * nrb; i += 256) rows_l[i] = i < n_b ? rows[i] : rows[0];
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int h = t; h < Hp; h += 256) {
+            float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
+            adam_update(wv, mv, vv, dzsum[h], alpha);
+            b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
+        }
+    }
+    const int gw = blockIdx.x * 4 + w;
+    if (gw >= n_active) return;
+    const int64_t U = (int64_t)nkt * NHT;
+    const int u0 = (int)((int64_t)gw * U / n_active), u1 = (int)((int64_t)(gw + 1) * U / n_active);
+    const float* sc_p = bn4;
+    const float* sh_p = bn4 + Kp;
+    const float* mu_p = bn4 + 2 * (int64_t)Kp;
+    const float* rs_p = bn4 + 3 * (int64_t)Kp;
+    float k_sc = 0.f, k_sh = 0.f, k_mu = 0.f, k_rs = 0.f, k_c = 0.f, pg = 0.f, pb = 0.f;
+    int cur_kt = -1, first_ht = 0;
+
+    auto flush = [&](int kt, int last_ht) __attribute__((always_inline)) {
+        float g_ = pg * k_rs, b_ = pb;
+        g_ += __shfl_xor(g_, 32);
+        b_ += __shfl_xor(b_, 32);
+        if (hi == 0) {
+            float* g0 = gbs + (int64_t)kt * 128;   // [slot][2][32]
+            if (first_ht == 0) {
+                g0[jl] = g_; g0[32 + jl] = b_;
+                if (last_ht == NHT - 1) { g0[64 + jl] = 0.f; g0[96 + jl] = 0.f; }
+            } else {
+                g0[64 + jl] = g_; g0[96 + jl] = b_;
+            }
+        }
+    };
+    for (int u = u0; u < u1; ++u) {
+        const int kt = u / NHT, ht = u - kt * NHT;
+        if (kt != cur_kt) {   // wave-uniform
+            if (cur_kt >= 0) flush(cur_kt, NHT - 1);
+            const int k = kt * KT + jl;
+            const float sc = sc_p[k], sh = sh_p[k], mu = mu_p[k];
+            const float c = rintf(mu);
+            k_sc = sc; k_sh = fmaf(sc, c, sh); k_mu = mu - c; k_rs = rs_p[k];
+            k_c = c;
+            pg = 0.f; pb = 0.f;
+            cur_kt = kt;
+            first_ht = ht;
+        }
+        const int64_t base = (int64_t)u * 1024;
+        f32x4 wq[4], mq[4], vq[4];
+        {
+            const f32x4* wp = reinterpret_cast<const f32x4*>(w1s + base);
+            const f32x4* mp = reinterpret_cast<const f32x4*>(m1s + base);
+            const f32x4* vp = reinterpret_cast<const f32x4*>(v1s + base);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wq[q] = wp[q * 64 + lane];
+                mq[q] = (NTM & 1) ? __builtin_nontemporal_load(mp + q * 64 + lane) : mp[q * 64 + lane];
+                vq[q] = (NTM & 1) ? __builtin_nontemporal_load(vp + q * 64 + lane) : vp[q * 64 + lane];
+            }
+        }
+        // S[h][k] = sum_b dz[b][h] (x[b][k] - c_k): D[i = unit][j = SNP], two rows per MFMA, row blocks in order
+        f32x16 S = {0};
+        const int k = kt * KT + jl;
+        for (int rb = 0; rb < nrb; ++rb) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int b = rb * 32 + rowmap(s_, hi);
+                av[s_] = dz1[(int64_t)b * Hp + ht * 32 + jl];
+                bv[s_] = (float)X[(int64_t)rows_l[b] * pitch + k] - k_c;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) S = mfma32(av[s_], bv[s_], S);
+        }
+        f32x4* wp = reinterpret_cast<f32x4*>(w1s + base);
+        f32x4* mp = reinterpret_cast<f32x4*>(m1s + base);
+        f32x4* vp = reinterpret_cast<f32x4*>(v1s + base);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 ds4 = *reinterpret_cast<const f32x4*>(dzsum + ht * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float s_ = S[q * 4 + c], ds = ds4[c];
+                float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
+                pg = fmaf(wv, fmaf(-k_mu, ds, s_), pg);          // sum_h W (S - mu dzsum); rstd applied at the flush
+                pb = fmaf(wv, ds, pb);
+                const float g = fmaf(k_sc, s_, k_sh * ds);
+                adam_update_fast(wv, mv, vv, g, alpha);
+                wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
+            }
+            if (NTM & 4) __builtin_nontemporal_store(wq[q], wp + q * 64 + lane); else wp[q * 64 + lane] = wq[q];
+            if (NTM & 8) __builtin_nontemporal_store(mq[q], mp + q * 64 + lane); else mp[q * 64 + lane] = mq[q];
+            if (NTM & 8) __builtin_nontemporal_store(vq[q], vp + q * 64 + lane); else vp[q * 64 + lane] = vq[q];
+        }
+    }
+    if (u0 < u1) flush(cur_kt, (u1 - 1) % NHT);
+}
+
 // gamma/beta Adam from the per-wave partial sums left by l1_bwd_adam_kernel (fixed order: slot 0 + slot 1).
 __global__ void l1_gamma_beta_adam_kernel(int K, const float* __restrict__ gbs, float* __restrict__ gamma,
                                           float* __restrict__ beta, float* __restrict__ m_gamma,
@@ -769,7 +904,7 @@ extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32
 extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last,
                                   int n_steps, int K, int Kp, const float* gamma, const float* beta,
                                   float* mov_mean, float* mov_var, float* stats_ep, float* bn4, void* stream) {
-    if (batch < 1 || batch > LOC_MAX_BATCH || n_last < 1 || n_last > batch || n_steps < 1) {
+    if (batch < 1 || batch > LOC_BIG_BATCH_MAX || n_last < 1 || n_last > batch || n_steps < 1) {
         loc_set_error("loc_bn_epoch_stats: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
         return -1;
     }
@@ -848,8 +983,8 @@ static int l1_backward_main_impl(const uint8_t* X, int64_t x_pitch, const int32_
         loc_set_error("loc_l1_backward_adam: dropout on the BatchNorm output (--nlayers 1) needs --batch_size <= 32");
         return -1;
     }
-    if (n_b < 1 || n_b > LOC_MAX_BATCH) {
-        loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..%d", n_b, LOC_MAX_BATCH);
+    if (n_b < 1 || n_b > LOC_BIG_BATCH_MAX) {
+        loc_set_error("loc_l1_backward_adam: n_b=%d out of 1..%d", n_b, LOC_BIG_BATCH_MAX);
         return -1;
     }
     const int nkt = d->Kp / KT, nht = d->Hp / 32;
@@ -858,6 +993,29 @@ static int l1_backward_main_impl(const uint8_t* X, int64_t x_pitch, const int32_
     int n_active = grid * 4;
     if (n_active > nkt) n_active = nkt;
     grid = (n_active + 3) / 4;
+    if (n_b > LOC_MAX_BATCH) {
+        // more than 128 rows: row blocks streamed from L2 (l1_bwd_adam_big_kernel); dzsum goes through the first Hp
+        // floats of gb_scratch's tail, which is free until the kernel's own flushes (they write [0, 4*Kp))
+        if (in_mask) { loc_set_error("loc_l1_backward_adam: --nlayers 1 with dropout needs --batch_size <= 32"); return -1; }
+        float* dzsum = gb_scratch + 4 * (int64_t)d->Kp;
+        hipLaunchKernelGGL(dz_colsum_kernel, dim3((d->Hp + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz1,
+                           (n_b + 31) / 32 * 32, d->Hp, dzsum);
+        LOC_CHECK_LAUNCH();
+        const size_t lds_big = ((size_t)d->Hp + (size_t)(n_b + 31) / 32 * 32) * sizeof(float);
+#define LAUNCH_BWD_BIG(N)                                                                                      \
+    hipLaunchKernelGGL((l1_bwd_adam_big_kernel<N, 13>), dim3(grid), dim3(256), lds_big, (hipStream_t)stream, X, x_pitch, \
+                       rows, n_b, d->K, d->Kp, bn4, dz1, dzsum, w1s, m1s, v1s, gb_scratch, b1, m_b1, v_b1,     \
+                       alpha_tab, alpha_tab_len, lr, t_base, t_off, n_active);
+        switch (nht) {
+            case 2: LAUNCH_BWD_BIG(2) break;
+            case 4: LAUNCH_BWD_BIG(4) break;
+            case 8: LAUNCH_BWD_BIG(8) break;
+            default: loc_set_error("loc_l1_backward_adam: more than 32 rows need width 64/128/256 after padding (got %d)", d->Hp); return -1;
+        }
+#undef LAUNCH_BWD_BIG
+        LOC_CHECK_LAUNCH();
+        return 0;
+    }
     const int rb = (n_b + LOC_ROWS - 1) / LOC_ROWS;
     const size_t lds = rb == 1 ? ((size_t)32 * (d->Hp + 1) + 32) * sizeof(float)
                                : ((size_t)d->Hp * (32 * rb + 4) + d->Hp + 32 * rb) * sizeof(float);

@@ -302,13 +302,15 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
                                  adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off), gb.next_stats, gb.bn4);
         return;
     }
+    // RB = 0: the number of 32-row blocks is a run-time value (--batch_size > 128): wave w takes blocks w, w + 8, ...
+    constexpr int NP = RB == 0 ? 8 : (RB > 1 ? RB : 1);
     __shared__ float gt[32][33];
-    __shared__ float gtp[RB > 1 ? RB : 1][32][33];      // per-row-block partial tiles (RB > 1)
-    __shared__ float sbp[RB > 1 ? RB : 1][32];
-    __shared__ float hsm[32 * RB][8];
+    __shared__ float gtp[NP][32][33];                   // per-row-block (RB = 0: per-wave) partial tiles
+    __shared__ float sbp[NP][32];
+    __shared__ float hsm[RB == 0 ? 1 : 32 * RB][8];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
     const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;
-    constexpr int nrb = RB;                            // 32-row blocks in use (1 unless --batch_size > 32)
+    const int nrb = RB == 0 ? (n_b + 31) / 32 : RB;    // 32-row blocks in use (1 unless --batch_size > 32)
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
     const int n_tiles = (L - 1) * NHT * NHT;
 
@@ -357,6 +359,48 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
                         P[o] = bw; M[o] = bm; V[o] = bvv;
                     }
                 }
+            }
+        } else if constexpr (RB == 0) {
+            // run-time block count: wave w accumulates blocks w, w + 8, ... in order; the 8 per-wave tiles are then
+            // added in a fixed order
+            {
+                f32x16 g = {0};
+                float sb = 0.f;
+                for (int rb = w; rb < nrb; rb += 8) {
+                    float av[16], bv[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int b = 32 * rb + 2 * s + hi;
+                        av[s] = in2[(int64_t)b * Hp + kt * 32 + jl];
+                        bv[s] = dz2[(int64_t)b * Hp + nt * 32 + jl];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sb += bv[i];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gtp[w][rowmap(r, hi)][jl] = g[r];
+                sb += __shfl_xor(sb, 32);
+                if (hi == 0) sbp[w][jl] = sb;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = t + 512 * i;
+                float a = gtp[0][e >> 5][e & 31];
+#pragma unroll
+                for (int rb = 1; rb < 8; ++rb) a += gtp[rb][e >> 5][e & 31];
+                gt[e >> 5][e & 31] = a;
+            }
+            if (kt == 0 && t < 32) {
+                float sb = sbp[0][t];
+#pragma unroll
+                for (int rb = 1; rb < 8; ++rb) sb += sbp[rb][t];
+                const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + t;
+                float bw = P[o], bm = M[o], bvv = V[o];
+                adam_update(bw, bm, bvv, sb, alpha);
+                P[o] = bw; M[o] = bm; V[o] = bvv;
             }
         } else {
             // one wave per row block (their load latencies overlap); the RB partial tiles are added in a fixed order
@@ -419,13 +463,17 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         return;
     }
     // ---- head block
-    constexpr int nrow = 32 * nrb;
-    for (int i = t; i < 8 * nrow; i += 512) hsm[i >> 3][i & 7] = head_out[i];
-    __syncthreads();
+    const int nrow = 32 * nrb;
+    if constexpr (RB != 0) {
+        for (int i = t; i < 8 * nrow; i += 512) hsm[i >> 3][i & 7] = head_out[i];
+        __syncthreads();
+    }
+    // head_out[b][0..7] = {per-sample loss, dy1[0..1], y1[0..1], dy2[0..1], -}: from LDS, or (run-time block count) from L2
+    auto H = [&](int b, int c) -> float { return RB != 0 ? hsm[b][c] : head_out[(int64_t)b * 8 + c]; };
     const float* aL = acts + (int64_t)(L - 1) * blk;
     if (t == 0) {
         float s = 0.f;
-        for (int b = 0; b < n_b; ++b) s += hsm[b][0];
+        for (int b = 0; b < n_b; ++b) s += H(b, 0);
         loss_out[0] = s / (float)n_b;
     }
     if (t >= 64 && t < 72) {
@@ -434,13 +482,13 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         int64_t off;
         if (q < 4) {            // dWb[i][j] = sum_b y1[b][i] dy2[b][j]
             const int i = q >> 1, j = q & 1;
-            for (int b = 0; b < nrow; ++b) g += hsm[b][3 + i] * hsm[b][5 + j];
+            for (int b = 0; b < nrow; ++b) g += H(b, 3 + i) * H(b, 5 + j);
             off = off_wb + q;
         } else if (q < 6) {     // dbb[j] = sum_b dy2[b][j]
-            for (int b = 0; b < nrow; ++b) g += hsm[b][5 + (q - 4)];
+            for (int b = 0; b < nrow; ++b) g += H(b, 5 + (q - 4));
             off = off_bb + (q - 4);
         } else {                // dba[c] = sum_b dy1[b][c]
-            for (int b = 0; b < nrow; ++b) g += hsm[b][1 + (q - 6)];
+            for (int b = 0; b < nrow; ++b) g += H(b, 1 + (q - 6));
             off = off_ba + (q - 6);
         }
         float wv = P[off], mv = M[off], vv = V[off];
@@ -451,9 +499,9 @@ __global__ __launch_bounds__(512) void stack_dw_all_kernel(
         float g0 = 0.f, g1 = 0.f;
 #pragma unroll 8
         for (int b = 0; b < nrow; ++b) {
-            const float av = aL[b * Hp + k];
-            g0 = fmaf(av, hsm[b][1], g0);
-            g1 = fmaf(av, hsm[b][2], g1);
+            const float av = aL[(int64_t)b * Hp + k];
+            g0 = fmaf(av, H(b, 1), g0);
+            g1 = fmaf(av, H(b, 2), g1);
         }
         const int64_t o = off_wa + 2 * k;
         float w0 = P[o], m0 = M[o], v0 = V[o], w1 = P[o + 1], m1 = M[o + 1], v1 = V[o + 1];
@@ -568,8 +616,8 @@ extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slo
                                       int64_t off_wa, int64_t off_ba, int64_t off_wb, int64_t off_bb,
                                       float* loss_out, const float* alpha_tab, int alpha_tab_len, const float* lr,
                                       const int* t_base, int t_off, const loc_gb_tail* gb, void* stream) {
-    if (n_b < 1 || n_b > LOC_MAX_BATCH || n_b > slot_rows) {
-        loc_set_error("loc_stack_dw_adam: n_b=%d (limit %d), slot_rows=%d", n_b, LOC_MAX_BATCH, slot_rows);
+    if (n_b < 1 || n_b > LOC_BIG_BATCH_MAX || n_b > slot_rows) {
+        loc_set_error("loc_stack_dw_adam: n_b=%d (limit %d), slot_rows=%d", n_b, LOC_BIG_BATCH_MAX, slot_rows);
         return -1;
     }
     const int nht = Hp / 32;
@@ -585,7 +633,8 @@ extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slo
         case 1: LAUNCH_RB(N, 1) break;                                                                            \
         case 2: LAUNCH_RB(N, 2) break;                                                                            \
         case 3: LAUNCH_RB(N, 3) break;                                                                            \
-        default: LAUNCH_RB(N, 4) break;                                                                           \
+        case 4: LAUNCH_RB(N, 4) break;                                                                            \
+        default: LAUNCH_RB(N, 0) break;   /* more than 128 rows: run-time block count */                          \
     }
     SF_SWITCH(LAUNCH)
 #undef LAUNCH

@@ -16,8 +16,8 @@ Deliberate, documented deviations:
     (same content);
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
-  * --batch_size is limited to 128 rows (the reference default is 32; 33..128 needs a --width that pads to 64,
-    128 or 256 and --nlayers >= 4 with dropout) and --width to 512;
+  * --batch_size is limited to 4096 rows (the reference default is 32; above 32 it needs a --width that pads to 64,
+    128 or 256 and --nlayers >= 4 with dropout; above 128 the step is correct but not tuned) and --width to 512;
   * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """
@@ -56,7 +56,8 @@ def build_parser():
     p.add_argument("--jacknife_prop", default=0.05, type=float,
                    help="fraction of SNPs redrawn per jacknife replicate (default 0.05)")
     p.add_argument("--nboots", default=50, type=int, help="number of bootstrap / jacknife replicates (default 50)")
-    p.add_argument("--batch_size", default=32, type=int, help="minibatch size (default 32; 1..128 here)")
+    p.add_argument("--batch_size", default=32, type=int,
+                   help="minibatch size (default 32; 1..4096 here; above 32 needs a --width that pads to 64, 128 or 256)")
     p.add_argument("--max_epochs", default=5000, type=int, help="upper bound on training epochs (default 5000)")
     p.add_argument("--patience", type=int, default=100,
                    help="epochs without validation improvement before training stops (default 100)")

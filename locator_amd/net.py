@@ -16,7 +16,8 @@ from . import _lib
 ALPHA_TAB_LEN = 32769            # beyond this t the Adam bias correction is 1 to fp32 precision
 ADAM_B1, ADAM_B2 = 0.9, 0.999
 LOC_ROWS = 32
-LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step
+LOC_MAX_BATCH = 128      # include/locator_hip.h: four 32-row blocks per step (the row-block kernels)
+LOC_BIG_BATCH_MAX = 4096 # include/locator_hip.h: --batch_size limit (above 128: row blocks streamed from L2)
 LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when batch > 32
 LOC_MAX_FWD_GRID = 512
 LOC_GEMM_MIN_ROWS = {3: 1152, 2: 768, 1: 640}  # include/locator_hip.h, by bf16 pieces
@@ -112,9 +113,10 @@ class LocatorNet:
 
     def set_batch(self, batch_size):
         """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..128 rows run two to
-        four row blocks per weight tile (same weight traffic per step) on a 128-row activation scratch."""
-        if not 1 <= batch_size <= LOC_MAX_BATCH:
-            raise ValueError(f"--batch_size must be in 1..{LOC_MAX_BATCH} for the HIP path (got {batch_size})")
+        four row blocks per weight tile (same weight traffic per step) on a 128-row activation scratch; above 128 the
+        layer-1 backward streams its row blocks from L2 and the scratch grows to the batch (correct, not tuned)."""
+        if not 1 <= batch_size <= LOC_BIG_BATCH_MAX:
+            raise ValueError(f"--batch_size must be in 1..{LOC_BIG_BATCH_MAX} for the HIP path (got {batch_size})")
         if batch_size > LOC_ROWS:
             if self.d.L < 2:
                 raise ValueError("--batch_size > 32 needs --nlayers >= 2")
@@ -123,7 +125,13 @@ class LocatorNet:
                                  "(33..64, 97..128 or 225..256)")
             if self.drop_p > 0 and self.d.n_pre < 2:
                 raise ValueError("--batch_size > 32 with dropout needs --nlayers >= 4")
-        self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
+        if batch_size > LOC_MAX_BATCH:
+            self.slot_rows = (batch_size + 127) // 128 * 128
+            need = self.lib.loc_workspace_floats_batch(C.byref(self.d), int(batch_size))
+            if self.ws.numel() < need:
+                self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        else:
+            self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
         self._net = None
         return self.slot_rows
 

@@ -25,6 +25,10 @@ pytestmark = pytest.mark.gpu
     (900, 256, 4, 128, 300),   # --batch_size 128: four row blocks, last batch of 44 (two blocks)
     (400, 64, 6, 96, 200),     # --batch_size 96: three row blocks, last batch of 8
     (2048, 128, 4, 100, 230),  # --batch_size 100: fourth block holds 4 rows; last batch of 30
+    (300, 64, 4, 200, 450),    # --batch_size 200 (> 128: row blocks streamed from L2, 256-row scratch); last batch of 50
+    (1000, 256, 6, 256, 600),  # --batch_size 256 at the default width: eight row blocks; last batch of 88
+    (500, 128, 4, 300, 700),   # --batch_size 300: ten row blocks (run-time block count past the eight waves); last 100
+    (700, 256, 10, 129, 400),  # --batch_size 129: one row past the row-block kernels; last batch of 13
 ])
 def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     """3 epochs of fit (eager epoch 0, captured graph afterwards) vs oracle.fit with the same init,
@@ -168,7 +172,8 @@ def test_unsupported_configurations_are_rejected_with_messages():
     from locator_amd.train import EpochRunner
     tr, va = np.arange(6), np.arange(6, 8)
     with pytest.raises(ValueError, match="batch_size"):
-        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 129)
+        EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 4097)
+    EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 129)              # above 128 is accepted since round 3
     with pytest.raises(ValueError, match="batch_size"):
         EpochRunner(LocatorNet(X, Y, 40, 64, 4), tr, va, 0)
     with pytest.raises(ValueError, match="width"):
