@@ -44,6 +44,8 @@ extern "C" {
 #endif
 
 #define LOC_ROWS 32 /* rows per row block = MFMA M                                              */
+#define LOC_MAX_WIDTH 1024 /* --width limit.  Up to 512 (after padding to 64/128/256/512) the hidden stack is one fused
+                              launch; other widths, and everything above 512, take the per-layer kernels           */
 #define LOC_MAX_BATCH 128 /* largest --batch_size of the row-block kernels: four 32-row blocks per step */
 #define LOC_BIG_BATCH_MAX 4096 /* --batch_size limit: above LOC_MAX_BATCH the step streams its row blocks from L2
                                   (l1_bwd_adam_big_kernel, run-time block counts in the tail) - correct, not tuned */
@@ -57,7 +59,7 @@ typedef struct loc_dims {
     int K;     /* SNPs after filtering                        (traingen.shape[1], locator.py:318) */
     int Kp;    /* K rounded up to a multiple of 32            */
     int H;     /* --width                                     (locator.py:320)                    */
-    int Hp;    /* H rounded up to a multiple of 32 (<= 512)   */
+    int Hp;    /* H rounded up to a multiple of 32 (<= LOC_MAX_WIDTH) */
     int L;     /* --nlayers: number of Dense+ELU layers, >= 1 (locator.py:319-323)                */
     int n_pre; /* floor(L/2): ELU layers before Dropout       (locator.py:319); 0 for --nlayers 1:
                   Dropout then acts on the BatchNorm output and its keep mask is [rows][Kp]        */

@@ -19,8 +19,9 @@ extern "C" const char* loc_last_error(void) { return g_err; }
 extern "C" int loc_version(void) { return 1; }
 
 extern "C" int loc_make_dims(int K, int H, int L, loc_dims* out) {
-    if (K < 1 || H < 1 || H > 512 || L < 1) {
-        loc_set_error("loc_make_dims: need K >= 1, 1 <= width <= 512, nlayers >= 1 (got K=%d H=%d L=%d)", K, H, L);
+    if (K < 1 || H < 1 || H > LOC_MAX_WIDTH || L < 1) {
+        loc_set_error("loc_make_dims: need K >= 1, 1 <= width <= %d, nlayers >= 1 (got K=%d H=%d L=%d)", LOC_MAX_WIDTH, K, H,
+                      L);
         return -1;
     }
     out->K = K;

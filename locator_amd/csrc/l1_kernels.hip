@@ -162,6 +162,8 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
     constexpr int WF4 = NHT * 256;               // float4 per weight tile
     constexpr int NLD = (WF4 + 511) / 512;       // float4 loads per thread per tile
     constexpr int BUF = (Hp + 32) * LP;          // floats per LDS buffer: W rows then xhat rows
+    constexpr int NBUF = NHT > 16 ? 1 : 2;       // widths above 512: the tile no longer fits twice (2 x 152 KB): one buffer
+    constexpr int NTW = (NHT + 7) / 8;           // unit tiles per wave: w, w + 8, ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
@@ -225,8 +227,9 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
         }
     };
 
-    f32x16 acc0 = {0}, acc1 = {0};
-    const bool own0 = w < NHT, own1 = (w + 8) < NHT;
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = f32x16{0};
 
     int kt = blockIdx.x;
     if (kt < nkt) {
@@ -242,37 +245,40 @@ __global__ __launch_bounds__(512) void l1_fwd_partial_kernel(const uint8_t* __re
         const float* buf = smem + cur * BUF;
         const float* Wl = buf;
         const float* xh = buf + Hp * LP;
-        if (own0) {
+        if (w < NHT) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 a = *reinterpret_cast<const f32x4*>(xh + jl * LP + 8 * m + 4 * hi);
-                f32x4 b = *reinterpret_cast<const f32x4*>(Wl + (w * 32 + jl) * LP + 8 * m + 4 * hi);
-                acc0 = mfma32(a[0], b[0], acc0);
-                acc0 = mfma32(a[1], b[1], acc0);
-                acc0 = mfma32(a[2], b[2], acc0);
-                acc0 = mfma32(a[3], b[3], acc0);
-                if (own1) {
-                    f32x4 b2 = *reinterpret_cast<const f32x4*>(Wl + ((w + 8) * 32 + jl) * LP + 8 * m + 4 * hi);
-                    acc1 = mfma32(a[0], b2[0], acc1);
-                    acc1 = mfma32(a[1], b2[1], acc1);
-                    acc1 = mfma32(a[2], b2[2], acc1);
-                    acc1 = mfma32(a[3], b2[3], acc1);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (w + 8 * j < NHT) {
+                        f32x4 b = *reinterpret_cast<const f32x4*>(Wl + ((w + 8 * j) * 32 + jl) * LP + 8 * m + 4 * hi);
+                        acc[j] = mfma32(a[0], b[0], acc[j]);
+                        acc[j] = mfma32(a[1], b[1], acc[j]);
+                        acc[j] = mfma32(a[2], b[2], acc[j]);
+                        acc[j] = mfma32(a[3], b[3], acc[j]);
+                    }
                 }
             }
         }
-        if (has_next) store_lds(smem + (cur ^ 1) * BUF);
-        __syncthreads();
-        cur ^= 1;
+        if (NBUF == 1) {
+            __syncthreads();                     // everyone is done with the only buffer before it is refilled
+            if (has_next) store_lds(smem);
+            __syncthreads();
+        } else {
+            if (has_next) store_lds(smem + (cur ^ 1) * BUF);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     // D[i = row b][j = unit]: lane holds unit jl, rows rowmap(r, hi)
     float* pout = partial + (int64_t)blockIdx.x * 32 * Hp;
-    if (own0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + w * 32 + jl] = acc0[r];
-    }
-    if (own1) {
+    for (int j = 0; j < NTW; ++j) {
+        if (w + 8 * j < NHT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + (w + 8) * 32 + jl] = acc1[r];
+            for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + (w + 8 * j) * 32 + jl] = acc[j][r];
+        }
     }
 }
 
@@ -887,8 +893,13 @@ static int set_max_lds(F* func, size_t bytes) {
         case 7: MACRO(7); break;   case 8: MACRO(8); break;   case 9: MACRO(9); break;      \
         case 10: MACRO(10); break; case 11: MACRO(11); break; case 12: MACRO(12); break;    \
         case 13: MACRO(13); break; case 14: MACRO(14); break; case 15: MACRO(15); break;    \
-        case 16: MACRO(16); break;                                                          \
-        default: loc_set_error("%s: width %d unsupported (Hp must be 32..512)", __func__, 32 * (NHT_VALUE)); return -1; \
+        case 16: MACRO(16); break; case 17: MACRO(17); break; case 18: MACRO(18); break;    \
+        case 19: MACRO(19); break; case 20: MACRO(20); break; case 21: MACRO(21); break;    \
+        case 22: MACRO(22); break; case 23: MACRO(23); break; case 24: MACRO(24); break;    \
+        case 25: MACRO(25); break; case 26: MACRO(26); break; case 27: MACRO(27); break;    \
+        case 28: MACRO(28); break; case 29: MACRO(29); break; case 30: MACRO(30); break;    \
+        case 31: MACRO(31); break; case 32: MACRO(32); break;                               \
+        default: loc_set_error("%s: width %d unsupported (Hp must be 32..1024)", __func__, 32 * (NHT_VALUE)); return -1; \
     }
 
 extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, int K, int Kp,
@@ -934,7 +945,7 @@ static int l1_forward_impl(const uint8_t* X, int64_t x_pitch, const int32_t* row
     if (grid < 1) grid = 1;
     if (grid > nkt) grid = nkt;
     if (grid > LOC_MAX_FWD_GRID) grid = LOC_MAX_FWD_GRID;
-    const size_t lds = 2 * (size_t)(d->Hp + 32) * LP * sizeof(float);
+    const size_t lds = (nht > 16 ? 1 : 2) * (size_t)(d->Hp + 32) * LP * sizeof(float);
 #define LAUNCH_FWD(N)                                                                                      \
     {                                                                                                      \
         LOC_ENSURE_LDS((l1_fwd_partial_kernel<N>), lds);                                                   \

@@ -292,7 +292,11 @@ __global__ __launch_bounds__(512) void head_train_kernel(const float* __restrict
             g0 = fmaf(av, dy1s[b][0], g0);
             g1 = fmaf(av, dy1s[b][1], g1);
         }
-        float m0 = pm0, v0 = pv0, m1 = pm1, v1 = pv1;     // Hp <= 512 = blockDim: k == t
+        float m0 = pm0, v0 = pv0, m1 = pm1, v1 = pv1;     // the early request covers k == t (every k when Hp <= 512)
+        if (k != t) {                                       // widths above 512: second pass of the loop
+            m0 = m[off_wa + 2 * k]; v0 = v[off_wa + 2 * k];
+            m1 = m[off_wa + 2 * k + 1]; v1 = v[off_wa + 2 * k + 1];
+        }
         adam_update(w0, m0, v0, g0, alpha);
         adam_update(w1, m1, v1, g1, alpha);
         wa[2 * k] = w0; wa[2 * k + 1] = w1;
@@ -351,8 +355,13 @@ static int set_max_lds2(F* func, size_t bytes) {
         case 7: MACRO(7); break;   case 8: MACRO(8); break;   case 9: MACRO(9); break;      \
         case 10: MACRO(10); break; case 11: MACRO(11); break; case 12: MACRO(12); break;    \
         case 13: MACRO(13); break; case 14: MACRO(14); break; case 15: MACRO(15); break;    \
-        case 16: MACRO(16); break;                                                          \
-        default: loc_set_error("%s: width %d unsupported (Hp must be 32..512)", __func__, 32 * (NHT_VALUE)); return -1; \
+        case 16: MACRO(16); break; case 17: MACRO(17); break; case 18: MACRO(18); break;    \
+        case 19: MACRO(19); break; case 20: MACRO(20); break; case 21: MACRO(21); break;    \
+        case 22: MACRO(22); break; case 23: MACRO(23); break; case 24: MACRO(24); break;    \
+        case 25: MACRO(25); break; case 26: MACRO(26); break; case 27: MACRO(27); break;    \
+        case 28: MACRO(28); break; case 29: MACRO(29); break; case 30: MACRO(30); break;    \
+        case 31: MACRO(31); break; case 32: MACRO(32); break;                               \
+        default: loc_set_error("%s: width %d unsupported (Hp must be 32..1024)", __func__, 32 * (NHT_VALUE)); return -1; \
     }
 
 extern "C" int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out,

@@ -17,7 +17,7 @@ Deliberate, documented deviations:
   * --keep_weights writes `{stem}.weights.npz` (NumPy archive, Keras tensor orientation) because
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 4096 rows (the reference default is 32; above 32 it needs a --width that pads to 64,
-    128 or 256 and --nlayers >= 4 with dropout; above 128 the step is correct but not tuned) and --width to 512;
+    128 or 256 and --nlayers >= 4 with dropout; above 128 the step is correct but not tuned) and --width to 1024 (above 512: per-layer kernels);
   * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """
@@ -67,7 +67,7 @@ def build_parser():
                    help="draw missing calls from Binomial(2, site frequency) instead of counting them as 0")
     p.add_argument("--dropout_prop", default=0.25, type=float, help="dropout rate of the middle layer (default 0.25)")
     p.add_argument("--nlayers", default=10, type=int, help="number of hidden layers (default 10)")
-    p.add_argument("--width", default=256, type=int, help="units per hidden layer (default 256; at most 512 here)")
+    p.add_argument("--width", default=256, type=int, help="units per hidden layer (default 256; at most 1024 here)")
     p.add_argument("--out", help="stem of every output file")
     p.add_argument("--seed", default=None, type=int, help="NumPy seed for the train/validation split and SNP draws")
     p.add_argument("--gpu_number", default=None, type=str, help="restrict the run to this GPU index")

@@ -29,6 +29,9 @@ pytestmark = pytest.mark.gpu
     (1000, 256, 6, 256, 600),  # --batch_size 256 at the default width: eight row blocks; last batch of 88
     (500, 128, 4, 300, 700),   # --batch_size 300: ten row blocks (run-time block count past the eight waves); last 100
     (700, 256, 10, 129, 400),  # --batch_size 129: one row past the row-block kernels; last batch of 13
+    (300, 600, 3, 32, 70),     # --width 600 (> 512: per-layer kernels, 19 unit tiles, single-buffered layer-1 forward)
+    (97, 1024, 2, 16, 40),     # --width 1024, the limit: 32 unit tiles; K = 3 tiles + 1 SNP
+    (500, 520, 4, 32, 64),     # --width 520 pads to 544 (17 unit tiles)
 ])
 def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     """3 epochs of fit (eager epoch 0, captured graph afterwards) vs oracle.fit with the same init,
@@ -49,10 +52,21 @@ def test_fit_matches_oracle_on_odd_shapes(K, width, nlayers, batch, n_train):
     pref = O.copy_params(p)
     href, _ = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=batch, max_epochs=3, patience=100, drop_p=0.25,
                     perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s, :nb, :width])
-    assert maxerr(hist["loss"], href["loss"]) < 5e-4, (hist["loss"], href["loss"])
-    assert maxerr(hist["val_loss"], href["val_loss"]) < 5e-4
+    # 5e-4 on the epoch losses, 1e-4 on every weight.  Where a wide, freshly initialised network overshoots (width 600:
+    # the epoch loss goes 1.57 -> 2.45 -> 1.68) three epochs amplify fp32 round-off beyond that - one step of the same
+    # net matches the oracle to 7e-8 / 1e-6 - so the bar there is the fp32 NumPy oracle's own distance from the fp64 one
+    dl, dv = maxerr(hist["loss"], href["loss"]), maxerr(hist["val_loss"], href["val_loss"])
     errs = params_err(net.export_params(), pref)
-    assert max(errs.values()) < 1e-4, errs
+    if max(dl, dv) >= 5e-4 or max(errs.values()) >= 1e-4:
+        p32 = O.cast_params(p, np.float32)
+        h32, _ = O.fit(p32, x[tr], y[tr].astype(np.float32), x[va], y[va].astype(np.float32), batch_size=batch,
+                       max_epochs=3, patience=100, drop_p=0.25, perm_fn=lambda e: perms[e],
+                       mask_fn=lambda e, s, nb: masks[e][s, :nb, :width])
+        floor = max(maxerr(h32["loss"], href["loss"]), maxerr(h32["val_loss"], href["val_loss"]))
+        wfloor = max(params_err(p32, pref).values())
+        assert width > 512 and floor > 1e-4, (dl, dv, floor)       # only the wide, overshooting cases may need this
+        assert max(dl, dv) < 3 * floor + 5e-4, (dl, dv, floor)
+        assert max(errs.values()) < 3 * wfloor + 1e-4, (errs, wfloor)
     # padding of the width / SNP axes stayed exactly zero through training
     d, lay = net.d, net.lay
     flat = net.params.cpu().numpy()
@@ -167,7 +181,8 @@ def test_unsupported_configurations_are_rejected_with_messages():
         LocatorNet(X, Y, 40, 64, 0)
     LocatorNet(X, Y, 40, 64, 1)                                        # --nlayers 1 is accepted (round 3)
     with pytest.raises(_lib.LocatorHipError, match="width"):
-        LocatorNet(X, Y, 40, 600, 4)
+        LocatorNet(X, Y, 40, 1025, 4)
+    LocatorNet(X, Y, 40, 600, 4)                                       # --width above 512 is accepted (round 3)
     # --batch_size: 1..128; above 32 only on the fused-stack widths up to 256 and with Dropout after layer >= 2
     from locator_amd.train import EpochRunner
     tr, va = np.arange(6), np.arange(6, 8)
