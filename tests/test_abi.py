@@ -66,7 +66,7 @@ def test_dims_and_layout():
     with pytest.raises(_lib.LocatorHipError):
         _lib.make_dims(10, 256, 0)          # nlayers < 1
     with pytest.raises(_lib.LocatorHipError):
-        _lib.make_dims(10, 1024, 4)
+        _lib.make_dims(10, 1025, 4)            # LOC_MAX_WIDTH is 1024
 
 
 def test_w1s_index_is_a_bijection_and_matches_mfma_layout():
