@@ -267,3 +267,47 @@ def test_second_predict_with_unchanged_weights_reuses_the_image_and_any_change_r
     mask = torch.ones(32 * width, dtype=torch.uint8, device="cuda")
     net.train_step(rows, 32, 1, mask, loss)
     assert net._image_mode == 0
+
+
+_BITCMP = """
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from locator_amd import _lib
+if sys.argv[1] != "-":
+    _lib.use_library(sys.argv[1])
+from tests.gpu_util import build_net, make_problem
+from tests.test_gpu_gemm import run_gemm
+from tests.test_gpu_gemm_i8 import run_gemm_i8
+x, y, p, rng = make_problem(1000, 20000, 256, 2, seed=7)
+net = build_net(x, y, p)
+r = torch.from_numpy(rng.permutation(1000).astype(np.int32)).cuda()
+h = hashlib.sha256()
+for d in (3, 2):
+    for ut in (1, 2):
+        h.update(run_gemm_i8(net, r, 1000, d, unit_tiles=ut)[:1000].tobytes())
+for pcs in (3, 2, 1):
+    h.update(run_gemm(net, r, 1000, pcs)[:1000].tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_hand_counted_vmcnt_build_equals_the_drained_build_bit_for_bit(repo_root, tmp_path):
+    """the GEMM kernels issue their global loads from inline asm and count `s_waitcnt vmcnt(N)` by hand.
+    `make debug_drain` (part of build()) compiles the same kernels with every count replaced by vmcnt(0); both libraries
+    must give identical bytes on the same inputs - every int8 mode in both wave forms and every bf16 mode, K = 20,000
+    (main body and remainders of the unrolled loops).  Separate processes: one library per process."""
+    import os
+    import subprocess
+    import sys
+    drain = os.path.join(repo_root, "locator_amd", "liblocator_hip_drain.so")
+    if not os.path.exists(drain):
+        pytest.skip("locator_amd/liblocator_hip_drain.so not built (make -C locator_amd/csrc debug_drain)")
+    script = tmp_path / "bitcmp.py"
+    script.write_text(_BITCMP)
+    out = []
+    for lib in ("-", drain):
+        r = subprocess.run([sys.executable, str(script), lib, repo_root], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert out[0] == out[1], out
