@@ -155,8 +155,9 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
     a1 = ELU(BN(x) W1 + b1) for M rows at once.  flops = 2*M*K*H counted ONCE, however many int8 digits or bf16 pieces
     carry each fp32 weight; the denominator is the dense bf16-MFMA peak for every mode (int8 digits run on the i8 pipe
     at twice the bf16 rate: 3 digits cost 1.5 bf16-MFMA equivalents per product, 2 digits 1).  Shapes: M = every row of
-    the matrix (model.predict over all samples); M = 4096 rows drawn from it (the batched --jacknife: nboots x n_pred
-    perturbed rows of the same matrix in one predict, so genotype lines repeat and come from L2 / MALL); M = 4096
+    the matrix (model.predict over all samples); M = 4096 and M = 16384 (= LOC_PREDICT_CHUNK, what loc_predict launches at
+    a time) rows drawn from it (the batched --jacknife: nboots x n_pred perturbed rows of the same matrix in one predict, so
+    genotype lines repeat and come from L2 / MALL); M = 4096
     DISTINCT rows of a second synthetic matrix (every genotype byte streams from HBM once).  Per shape and mode: us =
     GEMM + its reduction, mean of `iters` back-to-back launches replayed from a graph (the sustained, clocked-down
     rate); us_prep = the once-per-predict weight conversion (not in us; frac_bf16_peak_incl_prep has it); burst_of_3 =
@@ -236,6 +237,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
     res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
                      "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
     res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)
+    res["jacknife_shape_16384_rows"] = shape(net.X, 16384, n_matrix, in_loop=False)     # one LOC_PREDICT_CHUNK
     if x_distinct is not None:
         res["distinct_4096_rows"] = shape(x_distinct, 4096, x_distinct.shape[0], in_loop=False)
     return res

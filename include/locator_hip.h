@@ -51,8 +51,9 @@ extern "C" {
                                   (l1_bwd_adam_big_kernel, run-time block counts in the tail) - correct, not tuned */
 #define LOC_BATCH_SLOT 128 /* rows per activation slot of the training scratch when batch > 32   */
 #define LOC_ROWS_TILE 128      /* rows per workgroup tile of the large-M layer-1 forward          */
-#define LOC_PREDICT_CHUNK 4096 /* rows per large-M launch inside loc_predict: 4096, not 1024 (more rows per launch =
-                                  fewer SNP groups = less partial-sum traffic: 0.135 -> 0.154 of bf16 peak at 3 pieces) */
+#define LOC_PREDICT_CHUNK 16384 /* rows per large-M launch inside loc_predict (more rows per launch = fewer SNP groups
+                                   = less partial-sum traffic, prologue and epilogue amortised: the int8 GEMM on the
+                                   batched --jacknife shape goes 0.50 -> 0.55 of the bf16 peak from 4096 to 16384 rows) */
 #define LOC_ROWS_BLOCKS 256    /* 128-row tiles the large-M scratch is sized for (one workgroup per CU)   */
 
 typedef struct loc_dims {

@@ -112,8 +112,8 @@ NORTH_STAR_REL = 1e-3
 @pytest.mark.parametrize("mode,reps", [("int8x3", 1), ("int8x3", 5), ("int8x2", 1), ("int8x2", 5), ("bf16x3", 1),
                                        ("bf16x3", 3), ("bf16x2", 1), ("bf16x1", 1)])
 def test_config2_predict_all_rows(config2, mode, reps):
-    """loc_predict over all 1000 rows, and over 3000 / 5000 (every row several times: more than one LOC_PREDICT_CHUNK of
-    4096 rows at 5000, the image converted once for both chunks), vs oracle.predict, plus the per-row validation
+    """loc_predict over all 1000 rows, and over 3000 / 5000 (every row several times; more than one LOC_PREDICT_CHUNK is
+    covered at small K in tests/test_gpu_gemm_i8.py), vs oracle.predict, plus the per-row validation
     distances.  The deviation of the predictions relative to the largest prediction is printed per mode and asserted
     against the north_star bound for every mode except plain bf16 weights."""
     x, y, p, train, test, pred = config2

@@ -269,6 +269,25 @@ def test_second_predict_with_unchanged_weights_reuses_the_image_and_any_change_r
     assert net._image_mode == 0
 
 
+def test_predict_over_more_rows_than_one_chunk():
+    """loc_predict walks LOC_PREDICT_CHUNK = 16,384 rows per large-M launch with ONE weight image: 40,000 rows drawn from
+    a 600-row matrix (two full chunks and a remainder of 7,232) against oracle.predict on the distinct rows."""
+    from oracle import locator_oracle as O
+    K, width, n_mat, n = 1500, 256, 600, 40_000
+    x, y, p, rng = make_problem(n_mat, K, width, 4, seed=41)
+    ref = O.predict(p, x)
+    for digits in (3, 2):
+        net = build_net(x, y, p, predict_digits=digits)
+        r = rng.integers(0, n_mat, n).astype(np.int32)
+        yhat = torch.zeros((n, 2), device="cuda")
+        net.predict_rows(torch.from_numpy(r).cuda(), n, yhat)
+        torch.cuda.synchronize()
+        got = yhat.cpu().numpy()
+        bar = 2e-5 if digits == 3 else 1e-3 * np.abs(ref).max()
+        assert maxerr(got, ref[r]) < bar, (digits, maxerr(got, ref[r]))
+        assert net._image_mode == 10 + digits
+
+
 _BITCMP = """
 import hashlib, sys
 import numpy as np, torch

@@ -103,7 +103,7 @@ def test_rows_forward_rejects_what_it_cannot_do():
 
 @pytest.mark.parametrize("K,width,nlayers,n", [(5830, 256, 10, 450), (2000, 128, 4, 1500), (300, 64, 3, 33)])
 def test_predict_large_m_matches_oracle_and_the_32_row_kernels(K, width, nlayers, n):
-    """loc_predict over more than 32 rows (bf16x3 layer 1, then one stack launch per 4096-row chunk) vs
+    """loc_predict over more than 32 rows (bf16x3 layer 1, then one stack launch per 16,384-row chunk) vs
     oracle.predict (2e-5 abs), and vs the same rows pushed through the 32-row fp32-MFMA kernels
     (predict_pieces = -1): both are fp32-exact contractions, so they agree to summation-order noise."""
     x, y, p, rng = make_problem(n, K, width, nlayers, seed=n)

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--blocks", default="0")
     ap.add_argument("--gemm-only", action="store_true", help="only the image-based GEMMs (l1_gemm.hip, l1_gemm_i8.hip)")
     ap.add_argument("--i8-only", action="store_true", help="only the int8 GEMM (l1_gemm_i8.hip)")
+    ap.add_argument("--matrix-rows", type=int, default=0,
+                    help="size of the genotype matrix the rows are drawn from (rows = arange(n) %% matrix_rows): the batched "
+                         "--jacknife re-reads a small matrix, so its lines come from L2 / MALL; 0 = every row distinct")
     ap.add_argument("--lib", default=None, help="another build of liblocator_hip.so (timing ablations)")
     ap.add_argument("--unit-tiles", type=int, default=0,
                     help="int8 GEMM: loc_tuning.gemm_i8_unit_tiles (1 = eight waves per workgroup, 2 = four waves with 512 registers)")
@@ -39,6 +42,8 @@ def main():
         _lib.use_library(os.path.abspath(a.lib))
     dev = torch.device("cuda:0")
     n_max = max(int(r) for r in a.rows.split(","))
+    if a.matrix_rows:
+        n_max = min(n_max, a.matrix_rows)
     g = torch.Generator(device="cpu").manual_seed(1)
     X = (torch.rand((n_max, (a.snps + 31) // 32 * 32), generator=g) < 0.3).to(torch.uint8).to(dev)
     Y = torch.zeros((n_max, 2), device=dev)
@@ -51,7 +56,7 @@ def main():
     partial = torch.empty(512 * 128 * d.Hp, device=dev)
     out = []
     for n in ([] if a.gemm_only or a.i8_only else [int(r) for r in a.rows.split(",")]):
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        rows = (torch.arange(n, dtype=torch.int32, device=dev) % n_max).contiguous()
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for blocks in [int(b) for b in a.blocks.split(",")]:
             for pieces in (3, 2, 1):
@@ -84,7 +89,7 @@ def main():
                 out.append(rec)
     # int8 image + GEMM (l1_gemm_i8.hip): digits = 3 exact (1.5 bf16-MFMA equivalents per product), 2 fast (1)
     for n in [int(r) for r in a.rows.split(",")]:
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        rows = (torch.arange(n, dtype=torch.int32, device=dev) % n_max).contiguous()
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for digits in (3, 2):
             if not lib.loc_l1_gemm_i8_supported(d.Hp, digits):
@@ -123,7 +128,7 @@ def main():
                 out.append(rec)
     # image-based GEMM (l1_gemm.hip): conversion once per sweep, then a pure matrix-pipe K loop
     for n in ([] if a.i8_only else [int(r) for r in a.rows.split(",")]):
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        rows = (torch.arange(n, dtype=torch.int32, device=dev) % n_max).contiguous()
         a1 = torch.empty(((n + 127) // 128 * 128, d.Hp), device=dev)
         for pieces in (3, 2, 1):
             if not lib.loc_l1_gemm_supported(d.Hp, pieces):
