@@ -310,6 +310,7 @@ class LocatorNet:
         if need and (self.l1_image is None or self.l1_image.numel() < need):
             # many rows: W1 is converted once per call into this buffer (include/locator_hip.h, loc_net.l1_image)
             self.l1_image = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._image_mode = 0           # a fresh buffer holds nothing
             self._net = None
         net = self._net or self.cnet()
         # predict_locs predicts twice with the same weights (locator.py:414, :441): the second call finds the image
