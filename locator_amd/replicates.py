@@ -169,7 +169,8 @@ class ReplicatePool:
     host_prepare  optional per-unit hook `f(unit, args) -> unit` run on a LOADER THREAD of the worker: the parent keeps
                   two units in flight per worker, so the host work of unit i + 1 (zarr slice + filters, 2 s per
                   150k-variant window) overlaps the fit of unit i instead of sitting on its critical path
-    unit_timeout  seconds a unit may spend in a worker after it reported ("start", i); a worker that exceeds it is
+    unit_timeout  seconds a unit may spend in a worker after it reported ("start", i), or an otherwise idle worker may
+                  spend on a unit's host work before that report; a worker that exceeds it is
                   killed (its exact process, never a pattern), the unit becomes an error record and a FRESH process
                   takes the slot - a hung (not dead) worker no longer blocks the run.  0 = no limit.
 
@@ -217,7 +218,7 @@ class ReplicatePool:
         p.start()
         b.close()                           # the parent keeps only its own end: EOF then means "the worker is gone"
         self.workers[a] = {"p": p, "gpu": gpu, "inflight": [], "active": None, "t_active": 0.0, "ready": False,
-                           "shared_sent": False, "t_spawn": t, "slot": self._slot}
+                           "shared_sent": False, "t_spawn": t, "slot": self._slot, "t_wait": t}
         self._slot += 1
 
     # ------------------------------------------------------------------ the run
@@ -304,6 +305,8 @@ class ReplicatePool:
                     i = next_index()
                     if i is None:
                         return
+                    if not w["inflight"]:
+                        w["t_wait"] = time.time()    # an idle worker starts waiting for this unit's host work now
                     w["inflight"].append(i)
                     attempts[i] = attempts.get(i, 0) + 1
                     tl["units"].setdefault(i, {}).update(gpu=w["gpu"], dispatched=time.time())
@@ -362,7 +365,7 @@ class ReplicatePool:
                     elif kind == "done":
                         if payload["unit_index"] in w["inflight"]:
                             w["inflight"].remove(payload["unit_index"])
-                        w["active"] = None
+                        w["active"], w["t_wait"] = None, time.time()
                         record(payload)
                     elif kind == "dead":
                         self.log(f"replicate worker on GPU {w['gpu']}: {payload}")
@@ -379,6 +382,13 @@ class ReplicatePool:
                                  f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
                         w["p"].kill()               # this exact process
                         bury(conn, f"timed out after {self.unit_timeout:g} s")
+                    elif (self.unit_timeout and w["active"] is None and w["inflight"]
+                          and now - w["t_wait"] > self.unit_timeout):
+                        # nothing fitting, yet the next unit never reported "start": its host work (loader thread) hangs
+                        self.log(f"replicate {units[w['inflight'][0]].get('name', '?')} on GPU {w['gpu']}: host work exceeded "
+                                 f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
+                        w["p"].kill()
+                        bury(conn, f"host work timed out after {self.unit_timeout:g} s")
         finally:
             for shm in handles:
                 shm.close()

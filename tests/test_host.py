@@ -209,6 +209,8 @@ def _slow_fit(unit, device="cpu"):
 
 def _slow_host_prepare(unit, args):
     import time
+    if unit.get("hang_host"):
+        time.sleep(3600)
     time.sleep(0.4)
     return dict(unit, host_done=True, host_pid=os.getpid(), args_seen=args.out)
 
@@ -620,3 +622,20 @@ def test_pool_kills_a_hung_worker_after_unit_timeout_and_requeues_what_it_had_on
     for i in (0, 2, 3, 5, 6):
         assert "error" not in res[i] and res[i]["value"] == 2 * i, res[i]
     assert any("exceeded --unit_timeout" in str(l) for l in logs)
+
+
+def test_pool_kills_a_worker_whose_host_phase_hangs():
+    """A unit whose zarr slice / filter (loader thread) never returns never reports "start": the idle worker is killed
+    after unit_timeout all the same, the unit becomes an error record and the rest of the run completes."""
+    import time
+    units = [dict(name=f"h{i}", replicate=i) for i in range(5)]
+    units[2]["hang_host"] = True
+    logs = []
+    t0 = time.time()
+    res = R.run_units(units, _Args(), _slow_fit, n_gpus=1, fits_per_gpu=2, host_prepare=_slow_host_prepare,
+                      log=logs.append, poll_s=0.1, unit_timeout=1.5)
+    assert time.time() - t0 < 60
+    assert "host work timed out" in res[2]["error"]
+    for i in (0, 1, 3, 4):
+        assert "error" not in res[i] and res[i]["value"] == 2 * i, res[i]
+    assert any("host work exceeded --unit_timeout" in str(l) for l in logs)
