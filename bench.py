@@ -325,6 +325,10 @@ def main():
     ap.add_argument("--no-l1-gemm", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
+    ap.add_argument("--lib", default=None, help="measurement switch: another build of liblocator_hip.so (make ablate_chain ...)")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="measurement switch: one layer-1 forward launch per step instead of chaining it into the "
+                         "previous step's layer-1 backward (locator_amd/csrc/l1_chain.hip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing)")
     ap.add_argument("--device-index", type=int, default=None,
                     help="testing: put every rank on this GPU instead of LOCAL_RANK")
@@ -336,6 +340,9 @@ def main():
         sys.exit(spawn_ranks(args))
     if args.selftest_launch:
         sys.exit(selftest_launch(args))
+    if args.lib:
+        from locator_amd import _lib as _loc_lib
+        _loc_lib.use_library(os.path.abspath(args.lib))
 
     import torch
     import torch.distributed as dist
@@ -384,7 +391,8 @@ def main():
                                   tuning={"l1b_nt_mask": args.nt_mask} if args.nt_mask else None)
             if args.l1_bwd_grid:
                 self.net.l1_bwd_grid = int(args.l1_bwd_grid)
-            self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph)
+            self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph,
+                                      chain=False if args.no_chain else None)
             self.cb = Callbacks(100, 1e-3)
             self.rng = np.random.default_rng(99 + replicate)
             self.stream = torch.cuda.Stream(device=dev) if R > 1 else torch.cuda.current_stream()
@@ -483,7 +491,8 @@ def main():
                                    f"batch {args.batch}, {n_train} train / {len(test)} validation",
                        "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + callbacks"
                                + ("" if R == 1 else f", of each of the {R} fits"),
-                       "width": H, "nlayers": 10, "graph": not args.no_graph, "replicates_per_gpu": R,
+                       "width": H, "nlayers": 10, "graph": not args.no_graph,
+                       "chained_steps": bool(fits[0].runner.chain), "replicates_per_gpu": R,
                        "replicates": ("single model" if world == 1 and R == 1 else
                                       f"{R} model(s) per GPU, bootstrap resample per replicate")},
             "us_per_minibatch_step": round(ms_epoch * 1e3 / steps_per_epoch / R, 2),

@@ -300,6 +300,20 @@ int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* 
                               const float* lr, const int* t_base, int t_off, int grid, const loc_tuning* tune,
                               void* stream);
 
+/* Layer-1 backward + Adam of one minibatch CHAINED with the layer-1 forward of the next one (width padding to 256,
+ * n_b <= 32; locator.py:367-376: consecutive steps of model.fit).  One pass over W1 / m / v: Adam on W1 and b1, the
+ * BatchNorm gamma / beta update of loc_l1_backward_adam, the next step's [scale|shift|mean|rstd] into bn4 (in place;
+ * bn_next_stats = [mean|var] of the next minibatch), and -- rows_next non-NULL -- partial[g][32][256] of the next
+ * minibatch's layer-1 pre-activations from the updated weights, g < min(grid, Kp/32) workgroups, for the reduction of
+ * loc_l1_forward.  rows_next NULL: backward only (last step of an epoch). */
+int loc_l1_chain_supported(int Hp);
+int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const int32_t* rows_next,
+                               int n_b_next, const loc_dims* d, float* bn4, const float* bn_next_stats, const float* dz1,
+                               float* w1s, float* m1s, float* v1s, float* gamma, float* beta, float* m_gamma,
+                               float* v_gamma, float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
+                               const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base, int t_off,
+                               int grid, float* partial, int64_t partial_floats, const loc_tuning* tune, void* stream);
+
 /* ---- hidden Dense(width, elu) layers + Dropout (locator.py:319-323) ---- */
 int loc_dense_forward(const float* in, const float* W, const float* b, int Hp, float* out, float* out_drop,
                       const uint8_t* mask, float keep_scale, void* stream);
@@ -367,6 +381,17 @@ int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int
 int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
                    float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0, void* ev_l1b1,
                    void* stream);
+/* The same step inside an epoch whose minibatches are known in advance (model.fit draws the epoch's permutation
+ * before its first step): this step's layer-1 backward also produces the NEXT minibatch's layer-1 partial sums
+ * (loc_l1_backward_adam_chain), and a step with fwd_done != 0 starts from the partial sums its predecessor left instead
+ * of running the layer-1 forward.  The epoch-level BN statistics are required (bn_ready is implied; bn_next_stats as in
+ * loc_train_step, mandatory with rows_next).  rows_next NULL = last step of the epoch.  Results equal loc_train_step's
+ * up to the summation order of the BatchNorm gamma / beta gradient and of the layer-1 partial sums.
+ * loc_train_chain_supported: width padding to 256, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output. */
+int loc_train_chain_supported(const loc_net* net);
+int loc_train_step_chain(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                         float* loss_out, const float* bn_next_stats, const int32_t* rows_next, int n_b_next,
+                         int fwd_done, void* ev_l1b0, void* ev_l1b1, void* stream);
 /* The workspace's bn4 block (where loc_bn_epoch_stats must leave step 0's values). */
 float* loc_workspace_bn4(const loc_net* net);
 /* Inference forward over n rows (any n >= 0): yhat[n][2]; dist[n] if with_targets.  More than 32 rows go

@@ -116,6 +116,11 @@ SIGNATURES = {
                                          C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp,
                                          C.c_int, vp, vp, C.c_int, vp, vp]),
     "loc_train_step": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
+    "loc_train_chain_supported": (C.c_int, [C.POINTER(Net)]),
+    "loc_train_step_chain": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "loc_l1_chain_supported": (C.c_int, [C.c_int]),
+    "loc_l1_backward_adam_chain": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, vp, vp] + [vp] * 12
+                                   + [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(Tuning), vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_predict_image_mode": (C.c_int, [C.POINTER(Net), C.c_int]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),

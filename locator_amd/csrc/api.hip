@@ -113,9 +113,24 @@ static int max_rows_of(const loc_net* net) {
     return s > LOC_BATCH_SLOT ? (s < LOC_BIG_BATCH_MAX ? s : LOC_BIG_BATCH_MAX) : (s > LOC_ROWS ? LOC_MAX_BATCH : LOC_ROWS);
 }
 
-extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
-                              float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
-                              void* ev_l1b1, void* stream) {
+// workgroups of the chained layer-1 kernel: one 8-wave workgroup where the plain backward runs two of 4 waves
+static int chain_grid_of(const loc_net* net) {
+    const int nkt = net->d.Kp / 32;
+    int g = net->l1_bwd_grid / 2;
+    if (g < 1) g = 1;
+    return g > nkt ? nkt : g;
+}
+
+extern "C" int loc_train_chain_supported(const loc_net* net) {
+    const loc_dims* d = &net->d;
+    const bool in_drop = net->drop_p > 0.f && d->n_pre == 0;
+    return d->L >= 2 && net->wht && loc_stack_fused_supported(d->Hp) && loc_l1_chain_supported(d->Hp) &&
+           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_grid_of(net) <= LOC_MAX_FWD_GRID;
+}
+
+static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                           float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0, void* ev_l1b1,
+                           bool chain, const int32_t* rows_next, int n_b_next, int fwd_done, void* stream) {
     const loc_dims* d = &net->d;
     const int slot = slot_of(net);
     const int max_b = max_rows_of(net);
@@ -155,7 +170,12 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
     if (!bn_ready)
         TRY(loc_bn_batch_stats(net->X, net->x_pitch, rows, n_b, d->K, d->Kp, P + lay.gamma, P + lay.beta,
                                P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
-    if (n_b > LOC_ROWS) {
+    if (chain && fwd_done) {
+        // the previous step's chained kernel left this minibatch's layer-1 partial sums: only add them up
+        const bool dr = use_drop && npre == 1;
+        TRY(loc_l1_reduce_launch_drop(w.partial, chain_grid_of(net), 32, Hp, P + lay.b1, act(1), dr ? w.adrop : nullptr,
+                                      dr ? mask : nullptr, ks, stream));
+    } else if (n_b > LOC_ROWS) {
         // large-M forward, exact fp32 products (3 bf16 pieces); fills whole 128-row tiles of the activation slot
         TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
                                 w.partial_floats, act(1), 3, 0, &net->tune, stream));
@@ -176,6 +196,20 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                                        P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, slot, rows, net->Y,
                                        w.acts, w.adrop, w.dz, w.head_out, &net->tune, stream));
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
+        if (chain) {
+            // layer-1 backward + Adam (W1, b1, gamma, beta, the next step's scale/shift) and -- rows_next given -- the
+            // next minibatch's layer-1 forward partial sums from the weights while they are in registers
+            TRY(loc_l1_backward_adam_chain(net->X, net->x_pitch, rows, n_b, rows_next, n_b_next, d, w.bn4, bn_next_stats,
+                                           dzl(1), P + lay.w1, M + lay.w1, V + lay.w1, P + lay.gamma, P + lay.beta,
+                                           M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta, P + lay.b1,
+                                           M + lay.b1, V + lay.b1, at, atl, net->lr, net->t_base, t_off,
+                                           chain_grid_of(net), w.partial, w.partial_floats, &net->tune, stream));
+            if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
+            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M,
+                                       V, net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
+                                       net->lr, net->t_base, t_off, nullptr, stream));
+            return 0;
+        }
         TRY(loc_l1_backward_adam_main(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,
                                       V + lay.w1, P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr,
                                       net->t_base, t_off, net->l1_bwd_grid, &net->tune, stream));
@@ -231,6 +265,30 @@ extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, 
                              P + lay.b1, M + lay.b1, V + lay.b1, w.gbs, at, atl, net->lr, net->t_base, t_off,
                              net->l1_bwd_grid, bn_next_stats, w.bn4, ev_l1b1, &net->tune, stream));
     return 0;
+}
+
+extern "C" int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                              float* loss_out, int bn_ready, const float* bn_next_stats, void* ev_l1b0,
+                              void* ev_l1b1, void* stream) {
+    return train_step_impl(net, rows, n_b, t_off, mask, loss_out, bn_ready, bn_next_stats, ev_l1b0, ev_l1b1, false,
+                           nullptr, 0, 0, stream);
+}
+
+extern "C" int loc_train_step_chain(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
+                                    float* loss_out, const float* bn_next_stats, const int32_t* rows_next,
+                                    int n_b_next, int fwd_done, void* ev_l1b0, void* ev_l1b1, void* stream) {
+    if (!loc_train_chain_supported(net)) {
+        loc_set_error("loc_train_step_chain: needs width 225..256, nlayers >= 2, --batch_size <= 32 and no Dropout on the "
+                      "BatchNorm output (loc_train_chain_supported)");
+        return -1;
+    }
+    if (n_b > LOC_ROWS) { loc_set_error("loc_train_step_chain: n_b=%d out of 1..32", n_b); return -1; }
+    if (rows_next && !bn_next_stats) {
+        loc_set_error("loc_train_step_chain: rows_next needs the next minibatch's batch statistics");
+        return -1;
+    }
+    return train_step_impl(net, rows, n_b, t_off, mask, loss_out, 1, bn_next_stats, ev_l1b0, ev_l1b1, true, rows_next,
+                           n_b_next, fwd_done, stream);
 }
 
 extern "C" int loc_predict_image_mode(const loc_net* net, int n) {

@@ -114,6 +114,10 @@ int gm_launch_cvec(const float* cpart, int nkt64, float* cvec8, void* stream);
 int gm_launch_reduce(const float* partial, int G, int64_t MH, const float* cvec8, const float* b1, float* a1,
                      void* stream);
 
+// l1_kernels.hip: the layer-1 reduction alone (partial sums of G groups -> a1, optional Dropout on a1)
+int loc_l1_reduce_launch_drop(const float* partial, int G, int rows_p, int Hp, const float* b1, float* a1, float* a1_drop,
+                              const uint8_t* mask, float keep_scale, void* stream);
+
 // Raises a kernel's dynamic-LDS limit.  The limit is an attribute of the function PER DEVICE, so the "largest value
 // set so far" is remembered per (call site = kernel instantiation, device); the call is idempotent, which makes the
 // unsynchronised cache benign.  FUNC may hold template commas: wrap it in parentheses.

@@ -1,0 +1,407 @@
+// Layer-1 backward + Adam of minibatch t CHAINED with the layer-1 forward of minibatch t + 1, width 256
+// (reference: one `model.fit` step after another, /root/reference/locator/locator.py:367-376; layer 1 is
+// BatchNormalization + Dense(width, elu), :318-320).
+//
+// The backward kernel of l1_kernels.hip holds every updated weight W1' in registers once per step; the next step's
+// forward contracts the same W1' with the next minibatch's xhat.  Run as two kernels the forward re-reads all of W1
+// (102 MB at 100k SNPs: 24 us of a 192 us step).  Here the weight tile is used for the next forward while it is
+// still in registers, so a step streams W1 / m / v exactly once (read + write) and the separate forward launch
+// disappears for every step but the first of an epoch.
+//
+// What makes that legal: xhat_{t+1}[b][k] = gamma'_k * (x - mu_k) * rstd_k + beta'_k needs the gamma / beta that step t
+// itself updates, and their gradients reduce over ALL units of SNP k.  So one workgroup owns whole k-tiles: wave w
+// (of 8) streams unit tile w of every k-tile of the workgroup's range,
+//     dW^T[h][k]   = sum_b dZ[b][h] xhat[b][k]            (A = dZ from LDS, B = xhat registers)      -> Adam on W, m, v
+//     dxhat[b][k]  = sum_h dZ[b][h] W[h][k]  (this wave's 32 units) -> (sum_b dxhat*xn, sum_b dxhat) per SNP -> LDS
+//     --- one LDS-only barrier per k-tile (the weight prefetch stays in flight across it) ---
+//     every wave adds the 8 partial sums in wave order, applies Adam to gamma_k / beta_k (wave 0 stores them and the
+//     next step's [scale|shift|mean|rstd]), builds xhat_{t+1} for the tile, and contracts it with its W' tile:
+//     z_{t+1}[b][h] += sum_k xhat_{t+1}[b][k] W'[k][h]   (A = xhat_{t+1}, lane = row; B = W' through a 4 KB per-wave
+//     LDS transpose: the accumulator layout has lane = SNP, the B operand needs lane = unit)
+// and the workgroup leaves partial[g][32][256] for l1_reduce_kernel, exactly like l1_fwd_partial_kernel.
+// Same arithmetic per weight as l1_bwd_adam_kernel (fp32 MFMA, Adam with v_rcp / v_sqrt); the gamma / beta gradient is
+// the sum of 8 per-wave partials instead of 2 per-range partials (a different, equally fixed summation order).
+#include "common.h"
+
+#define KT 32
+
+// timing ablations (make ablate_chain A=<bits>): results are WRONG with any bit set; they only answer "what does this
+// part of the loop cost".  1 = no barrier, 2 = no per-tile small global loads, 4 = no next-forward part, 8 = no dxhat MFMAs,
+// 16 = no Adam arithmetic, 32 = no weight stores, 64 = no dW MFMAs
+#ifndef LOC_CHAIN_ABLATE
+#define LOC_CHAIN_ABLATE 0
+#endif
+
+__device__ __forceinline__ void ch_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void ch_adam_fast(float& w, float& m, float& v, float g, float alpha) {
+    m = m + (g - m) * ADAM_C1;
+    v = v + (g * g - v) * ADAM_C2;
+    w = w - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
+}
+
+// Vector-memory loads the compiler does not track, with hand-counted s_waitcnt (as in l1_gemm.hip).  Left to itself the
+// compiler waits for the 12 KB prefetch it has just issued before the first use of the CURRENT register set (its
+// per-register wait counts are merged conservatively around the loop), so nothing overlaps.  The "memory" clobbers keep
+// these loads, the compiler's own stores and the waits in program order, which is what the counts below rely on.
+// 16 bytes at (wave-uniform base) + (32-bit byte offset of the lane) + OFF: one offset register serves W1, m and v
+template <int OFF, bool NT>
+__device__ __forceinline__ void ch_gload16(f32x4& v, const float* base, uint32_t voff) {
+    if (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+template <int OFF, bool NT>
+__device__ __forceinline__ void ch_gstore16(const f32x4& v, float* base, uint32_t voff) {
+    if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
+// 4 bytes at (wave-uniform base) + (32-bit byte offset of the lane)
+__device__ __forceinline__ void ch_gload4(uint32_t& v, const float* base, uint32_t voff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ch_gload8(uint32_t& v0, uint32_t& v1, const void* p) {
+    uint2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    v0 = v.x; v1 = v.y;
+}
+// wait until at most N vector-memory operations are outstanding; the operands tie the registers the wait protects, so
+// no use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4]) {
+    asm volatile("s_waitcnt vmcnt(%12)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ch_wait_small(uint32_t& a, uint32_t& b, uint32_t& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
+constexpr int CH_HP = 256, CH_PZ = CH_HP + 1, CH_TP = 33;
+constexpr int CH_SM = 896;   // floats of one k-tile's small operands in LDS (see `sm` in the kernel)
+constexpr size_t CH_LDS_FLOATS = 32 * CH_PZ + 64 + 8 * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * CH_SM;
+
+template <int NTM>
+__global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
+    const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b,
+    const int32_t* __restrict__ rows_next, int n_b_next, int K, int Kp, float* bn4,
+    const float* __restrict__ next_stats, const float* __restrict__ dz1, float* __restrict__ w1s,
+    float* __restrict__ m1s, float* __restrict__ v1s, float* __restrict__ gamma, float* __restrict__ beta,
+    float* __restrict__ m_gamma, float* __restrict__ v_gamma, float* __restrict__ m_beta, float* __restrict__ v_beta,
+    float* __restrict__ b1, float* __restrict__ m_b1, float* __restrict__ v_b1, const float* __restrict__ alpha_tab,
+    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off,
+    float* __restrict__ partial_out) {
+    constexpr int NHT = 8, Hp = CH_HP, PZ = CH_PZ, TP = CH_TP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dzl = smem;                                          // [32][PZ]   dZ of this step
+    int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);        // [32]
+    int* rown_l = rows_l + 32;                                  // [32]       rows of the next minibatch
+    float* Tt = reinterpret_cast<float*>(rown_l + 32);          // [8][32][TP] per-wave W' tile, [SNP][unit]
+    float* red = Tt + 8 * 32 * TP;                              // [2][8][64]  per-wave (dgamma | dbeta) partials, by k-tile parity
+    float* ssl = red + 2 * 8 * 64;                              // [8][64]     per-wave (scale' | shift') of the next step
+    // [2][CH_SM] the small operands of a k-tile, fetched two tiles ahead by seven loader waves (one to three load
+    // instructions each instead of 26 per wave): bytes 0..1023 genotype tile of this minibatch [32 rows][32 SNPs],
+    // 1024..2047 the same for the next minibatch, then floats [scale|shift|mean|rstd][32], (gamma|beta), their Adam
+    // m, v [64] each, next [mean|var][32]
+    float* sm = ssl + 8 * 64;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int jl = lane & 31, hi = lane >> 5;
+    const int nkt = Kp / KT;
+    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
+    const bool chain = rows_next != nullptr;
+
+    // byte offset of this lane's first 16 bytes of unit (kt, w) in each of W1S / m / v  (Kp * 1024 < 2^32: checked by the launcher)
+    auto unit_off = [&](int kt) { return (uint32_t)(((uint32_t)kt * NHT + w) * 4096u + lane * 16u); };
+    auto load_unit = [&](int kt, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
+        // 12 loads, always: the wait counts below depend on it
+        const uint32_t o = unit_off(kt);
+        ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0>(vq[0], v1s, o);
+        ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0>(vq[1], v1s, o);
+        ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0>(vq[2], v1s, o);
+        ch_gload16<3072, (NTM & 2) != 0>(wq[3], w1s, o); ch_gload16<3072, (NTM & 1) != 0>(mq[3], m1s, o); ch_gload16<3072, (NTM & 1) != 0>(vq[3], v1s, o);
+    };
+    // The first unit is requested before anything else; the prologue ends with vmcnt(0).
+    f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
+    if ((int)blockIdx.x < nkt) load_unit(blockIdx.x, wA, mA, vA);
+
+    for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
+    if (t < 32) {
+        rows_l[t] = t < n_b ? rows[t] : 0;
+        rown_l[t] = (chain && t < n_b_next) ? rows_next[t] : 0;
+    }
+    __syncthreads();
+
+    // gamma (lanes 0..31) or beta (lanes 32..63) of SNP jl of the tile: one Adam per lane.  beta / m_beta / v_beta sit Kp
+    // floats behind gamma / m_gamma / v_gamma (loc_param_layout; checked by the launcher): one wave-uniform base each
+    const int gbo = hi * Kp;
+    (void)beta; (void)m_beta; (void)v_beta;
+    // loader roles (wave-uniform): waves 0, 1 the genotype tile (8 bytes per lane), 2, 3 the next minibatch's, 4 bn4,
+    // 5 gamma / beta + moments, 6 the next minibatch's batch statistics.  fetch() issues the global loads of tile kt,
+    // stage() puts them into sm[buf] an iteration later (under load a small load takes about as long as a big one).
+    uint32_t ld0 = 0u, ld1 = 0u, ld2 = 0u;
+    auto fetch = [&](int kt) {
+        const int k = kt * KT + jl;
+        if (w <= 3) {
+            const int pc = (w & 1) * 64 + lane;                       // 8-byte piece of the [32 rows][32 bytes] tile
+            const int row = w <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];
+            if (w <= 1 || chain) ch_gload8(ld0, ld1, X + (int64_t)row * pitch + (int64_t)kt * KT + 8 * (pc & 3));
+        } else if (w == 4) {
+            ch_gload4(ld0, bn4, 4u * (uint32_t)(hi * Kp + k));
+            ch_gload4(ld1, bn4, 4u * (uint32_t)((2 + hi) * Kp + k));
+        } else if (w == 5) {
+            const uint32_t o = 4u * (uint32_t)(gbo + k);
+            ch_gload4(ld0, gamma, o); ch_gload4(ld1, m_gamma, o); ch_gload4(ld2, v_gamma, o);
+        } else if (w == 6) {
+            if (chain) ch_gload4(ld0, next_stats, 4u * (uint32_t)(hi * Kp + k));
+        }
+    };
+    auto stage = [&](int buf) {
+        float* b = sm + buf * CH_SM;
+        if (w <= 1) {
+            // this minibatch's tile goes in TRANSPOSED, [SNP][32 bytes], the byte of row b at position
+            // 16 * ((b >> 2) & 1) + (b & 3) + 4 * (b >> 3): lane (SNP jl, half hi) then reads its 16 rows rowmap(r, hi),
+            // r = 0..15, as one 16-byte word
+            uint8_t* xb = reinterpret_cast<uint8_t*>(b);
+            const int pc = (w & 1) * 64 + lane, row = pc >> 2, snp0 = 8 * (pc & 3);
+            const int pos = 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xb[(snp0 + e) * 32 + pos] = (uint8_t)(((e < 4 ? ld0 : ld1) >> (8 * (e & 3))) & 255u);
+        } else if (w <= 3) {
+            uint2 v; v.x = ld0; v.y = ld1;
+            *reinterpret_cast<uint2*>(b + 256 + ((w & 1) * 64 + lane) * 2) = v;
+        } else if (w == 4) {
+            b[512 + lane] = bitsf(ld0);
+            b[576 + lane] = bitsf(ld1);
+        } else if (w == 5) {
+            b[640 + lane] = bitsf(ld0); b[704 + lane] = bitsf(ld1); b[768 + lane] = bitsf(ld2);
+        } else if (w == 6) {
+            b[832 + lane] = bitsf(ld0);
+        }
+    };
+    {
+        const int G = gridDim.x, kt = blockIdx.x;
+        if (kt < nkt) {
+            fetch(kt);
+            ch_wait_small<0>(ld0, ld1, ld2);
+            stage(0);
+        }
+        if (kt + G < nkt) fetch(kt + G);                      // staged at the end of the first iteration
+        ch_wait_small<0>(ld0, ld1, ld2);
+        ch_wait_unit<0>(wA, mA, vA);
+    }
+    __syncthreads();
+
+    // bias of layer 1: db1[h] = sum_b dZ[b][h]   (workgroup 0, wave w <-> unit tile w)
+    if (blockIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + w * 32 + jl];
+        s += __shfl_xor(s, 32);
+        if (hi == 0) {
+            const int h = w * 32 + jl;
+            float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
+            adam_update(wv, mv, vv, s, alpha);
+            b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
+        }
+    }
+
+    float* Tw = Tt + w * 32 * TP;
+    float* ssw = ssl + w * 64;
+    const bool row_next_ok = chain && jl < n_b_next;
+
+    f32x16 facc = {0};
+
+    // Vector-memory operations of one iteration, in program order (hand-counted waits depend on it):
+    //   12 prefetch loads (kt_next >= 0) | 12 stores of this unit | 0..3 small loads of tile + 2 | barrier | 0..5 small stores
+    auto step = [&](int kt, int kt_next, int kt_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
+                    f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
+        const int k = kt * KT + jl;
+        // this tile's small operands from LDS
+        const float* smc = sm + par * CH_SM;
+        const uint8_t* xt = reinterpret_cast<const uint8_t*>(smc);
+        const u32x4 xp = *reinterpret_cast<const u32x4*>(xt + jl * 32 + hi * 16);      // 16 rows of SNP jl, packed
+        auto xv = [&](int r) { return (float)((xp[r >> 2] >> (8 * (r & 3))) & 255u); };
+        const float sc = smc[512 + jl], sh = smc[544 + jl], mu = smc[576 + jl], rs = smc[608 + jl];
+        float pv = smc[640 + lane], pm = smc[704 + lane], pvv = smc[768 + lane];
+        float nmu = smc[832 + jl], nvar = smc[864 + jl];
+        const u32x4 xr = *reinterpret_cast<const u32x4*>(smc + 256 + jl * 8 + 4 * hi);
+        // this unit's 12 loads are older than the previous iteration's 12 stores and the 12 loads just issued; on the last
+        // tile nothing is issued and everything is awaited.  ONE tied wait for both cases: two would meet in a phi and
+        // cost a copy of the whole register set
+        if (kt_next >= 0) load_unit(kt_next, wn, mn, vn);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ch_wait_unit<24>(wq, mq, vq);
+
+        // dxhat tile of this wave's 32 units: D[i = row b][j = SNP], contraction over units h = w*32 + rowmap(s, hi)
+        f32x16 dx = {0};
+#if !(LOC_CHAIN_ABLATE & 8)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dx = mfma32(dzl[jl * PZ + w * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
+#endif
+        {
+            float pg = 0.f, pb = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // rows beyond the minibatch need no mask here or in dW below: their dZ rows are zero (so is dxhat), and the
+                // genotype bytes staged for them (row 0's) are finite
+                const float xn = (xv(r) - mu) * rs;
+                pg = fmaf(dx[r], xn, pg);
+                pb += dx[r];
+            }
+            pg += __shfl_xor(pg, 32);
+            pb += __shfl_xor(pb, 32);
+            red[(par * 8 + w) * 64 + lane] = hi ? pb : pg;
+        }
+        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
+        f32x16 g = {0};
+#pragma unroll
+        for (int s = 0; s < ((LOC_CHAIN_ABLATE & 64) ? 1 : 16); ++s) {
+            const float xh = fmaf(xv(s), sc, sh);
+            g = mfma32(dzl[rowmap(s, hi) * PZ + w * 32 + jl], xh, g);
+        }
+        // Adam on the weight tile, stores, and the tile's transpose for the next forward
+        const uint32_t so = unit_off(kt);
+        auto adam4 = [&](int q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
+#if LOC_CHAIN_ABLATE & 16
+                wv += g[q * 4 + c];
+#else
+                ch_adam_fast(wv, mv, vv, g[q * 4 + c], alpha);
+#endif
+                wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
+            }
+        };
+        // 12 stores, always
+#if LOC_CHAIN_ABLATE & 32
+        adam4(0); adam4(1); adam4(2); adam4(3);
+#else
+        adam4(0); ch_gstore16<0, (NTM & 4) != 0>(wq[0], w1s, so);    ch_gstore16<0, (NTM & 8) != 0>(mq[0], m1s, so);    ch_gstore16<0, (NTM & 8) != 0>(vq[0], v1s, so);
+        adam4(1); ch_gstore16<1024, (NTM & 4) != 0>(wq[1], w1s, so); ch_gstore16<1024, (NTM & 8) != 0>(mq[1], m1s, so); ch_gstore16<1024, (NTM & 8) != 0>(vq[1], v1s, so);
+        adam4(2); ch_gstore16<2048, (NTM & 4) != 0>(wq[2], w1s, so); ch_gstore16<2048, (NTM & 8) != 0>(mq[2], m1s, so); ch_gstore16<2048, (NTM & 8) != 0>(vq[2], v1s, so);
+        adam4(3); ch_gstore16<3072, (NTM & 4) != 0>(wq[3], w1s, so); ch_gstore16<3072, (NTM & 8) != 0>(mq[3], m1s, so); ch_gstore16<3072, (NTM & 8) != 0>(vq[3], v1s, so);
+#endif
+        if (chain && !(LOC_CHAIN_ABLATE & 4)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tw[jl * TP + rowmap(r, hi)] = wq[r >> 2][r & 3];   // T[SNP][unit]
+        }
+        // The next tile's small operands, requested at the end of the previous iteration, go to the other LDS buffer: they
+        // are older than that iteration's small stores, this one's 12 prefetch loads and its 12 stores.  Then the request
+        // for the tile after next.
+        if (kt_next >= 0 && !(LOC_CHAIN_ABLATE & 2)) {
+            ch_wait_small<24>(ld0, ld1, ld2);
+            stage(par ^ 1);
+            if (kt_next2 >= 0) fetch(kt_next2);
+        }
+#if !(LOC_CHAIN_ABLATE & 1)
+        // every wave's (dgamma | dbeta) partial of this k-tile and the next tile's small operands are in LDS; all reads
+        // of this tile's small operands are above this line, so the buffer is free for tile + 2 after it
+        ch_lds_barrier();
+#endif
+
+        float dsum = red[(par * 8 + 0) * 64 + lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) dsum += red[(par * 8 + w2) * 64 + lane];
+        adam_update(pv, pm, pvv, dsum, alpha);
+        const bool live = k < K;
+        if (w == 0 && live) { gamma[gbo + k] = pv; m_gamma[gbo + k] = pm; v_gamma[gbo + k] = pvv; }
+        if (chain && !(LOC_CHAIN_ABLATE & 4)) {
+            const float other = __shfl_xor(pv, 32);
+            const float gam = hi ? other : pv, bet = hi ? pv : other;
+            float rstd = 1.0f / sqrtf(nvar + BN_EPS);
+            float scn = gam * rstd;
+            float shn = bet - nmu * scn;
+            if (!live) { scn = 0.f; shn = 0.f; nmu = 0.f; rstd = 0.f; }
+            if (w == 0) {
+                bn4[(hi ? Kp : 0) + k] = hi ? shn : scn;
+                bn4[(int64_t)(2 + hi) * Kp + k] = hi ? rstd : nmu;
+            }
+            ssw[lane] = hi ? shn : scn;
+            __builtin_amdgcn_wave_barrier();
+            // xhat of the next minibatch for SNPs 16*hi + s of the tile (lane = row jl), times W'[SNP][unit = jl]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssw + 16 * hi + 4 * j);
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(ssw + 32 + 16 * hi + 4 * j);
+                const uint32_t xw = xr[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xb = (float)((xw >> (8 * e)) & 255u);
+                    const float a = row_next_ok ? fmaf(xb, s4[e], h4[e]) : 0.f;   // rows beyond the next minibatch: staged from row 0, unused
+                    facc = mfma32(a, Tw[(16 * hi + 4 * j + e) * TP + jl], facc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    // workgroup g owns k-tiles g, g + G, g + 2G, ...: at any moment the G workgroups stream one contiguous G * 32 KB
+    // window of W1 / m / v, which spreads over every HBM channel
+    {
+        const int G = gridDim.x;
+        for (int kt = blockIdx.x; kt < nkt; kt += 2 * G) {
+            auto nx = [&](int j) { return kt + j * G < nkt ? kt + j * G : -1; };
+            step(kt, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+            if (kt + G < nkt) step(kt + G, nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+        }
+    }
+    if (chain) {
+        // D[i = row b][j = unit]: lane holds unit w*32 + jl, rows rowmap(r, hi) -- the layout l1_reduce_kernel sums
+        float* pout = partial_out + (int64_t)blockIdx.x * 32 * Hp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + w * 32 + jl] = facc[r];
+    }
+}
+
+extern "C" int loc_l1_chain_supported(int Hp) { return Hp == CH_HP; }
+
+extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                          const int32_t* rows_next, int n_b_next, const loc_dims* d, float* bn4,
+                                          const float* bn_next_stats, const float* dz1, float* w1s, float* m1s,
+                                          float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
+                                          float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
+                                          const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
+                                          int t_off, int grid, float* partial, int64_t partial_floats,
+                                          const loc_tuning* tune, void* stream) {
+    if (d->Hp != CH_HP) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 256 (got %d)", d->Hp); return -1; }
+    if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..32", n_b); return -1; }
+    if (rows_next && (n_b_next < 1 || n_b_next > LOC_ROWS || !bn_next_stats)) {
+        loc_set_error("loc_l1_backward_adam_chain: the next minibatch needs 1..32 rows (got %d) and its batch statistics",
+                      n_b_next);
+        return -1;
+    }
+    if ((x_pitch % 16) != 0 || ((uintptr_t)X % 16) != 0) {
+        loc_set_error("loc_l1_backward_adam_chain: genotype rows must be 16-byte aligned (pitch %lld)", (long long)x_pitch);
+        return -1;
+    }
+    const int nkt = d->Kp / KT;
+    if (grid < 1) grid = 1;
+    if (grid > nkt) grid = nkt;
+    if (rows_next && (int64_t)grid * 32 * CH_HP > partial_floats) {
+        loc_set_error("loc_l1_backward_adam_chain: partial buffer too small for %d workgroups", grid);
+        return -1;
+    }
+    const size_t lds = CH_LDS_FLOATS * sizeof(float);
+    const int ntm = !tune || tune->l1b_nt_mask == 0 ? 13 : (tune->l1b_nt_mask < 0 ? 0 : tune->l1b_nt_mask);
+#define LAUNCH_CHAIN(M)                                                                                            \
+    {                                                                                                              \
+        LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M>), lds);                                                        \
+        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M>), dim3(grid), dim3(512), lds, (hipStream_t)stream, X, x_pitch, \
+                           rows, n_b, rows_next, n_b_next, d->K, d->Kp, bn4, bn_next_stats, dz1, w1s, m1s, v1s, gamma, \
+                           beta, m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr,   \
+                           t_base, t_off, partial);                                                                \
+    }
+    switch (ntm) {
+        case 0: LAUNCH_CHAIN(0) break;
+        case 9: LAUNCH_CHAIN(9) break;
+        case 15: LAUNCH_CHAIN(15) break;
+        default: LAUNCH_CHAIN(13) break;
+    }
+#undef LAUNCH_CHAIN
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

@@ -975,6 +975,16 @@ extern "C" int loc_l1_forward_in_dropout(const uint8_t* X, int64_t x_pitch, cons
                            in_mask, keep_scale, stream);
 }
 
+// reduction alone, with the optional Dropout on layer 1's output: the chained training step (l1_chain.hip) leaves
+// the partial sums of the NEXT minibatch, whose step then starts here
+int loc_l1_reduce_launch_drop(const float* partial, int G, int rows_p, int Hp, const float* b1, float* a1, float* a1_drop,
+                              const uint8_t* mask, float keep_scale, void* stream) {
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(rows_p * Hp / 64), dim3(256), 0, (hipStream_t)stream, partial, G,
+                       rows_p, Hp, b1, a1, a1_drop, mask, keep_scale);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
 // reduction of the large-M forward (l1_rows.hip): rows_p rows, no dropout
 int loc_l1_reduce_launch(const float* partial, int G, int rows_p, int Hp, const float* b1, float* a1, void* stream) {
     hipLaunchKernelGGL(l1_reduce_kernel, dim3(rows_p * Hp / 64), dim3(256), 0, (hipStream_t)stream, partial, G,

@@ -282,6 +282,24 @@ class LocatorNet:
                                            _ptr(loss_out), 1 if bn_ready else 0, _ptr(bn_next), ev0, ev1, _stream()),
                    "loc_train_step")
 
+    def chain_supported(self):
+        """True when consecutive steps of an epoch may be chained (loc_train_step_chain: the layer-1 backward of step t
+        also produces the layer-1 forward of step t + 1): width padding to 256, nlayers >= 2, batch <= 32, Dropout not
+        on the BatchNorm output."""
+        net = self._net or self.cnet()
+        return bool(self.lib.loc_train_chain_supported(C.byref(net)))
+
+    def train_step_chain(self, rows, n_b, t_off, mask, loss_out, bn_next, rows_next, n_b_next, fwd_done,
+                         ev0=None, ev1=None):
+        """train_step inside an epoch with epoch-level BN statistics: rows_next / n_b_next / bn_next describe the next
+        minibatch (None for the epoch's last step); fwd_done = the previous chained step already left this
+        minibatch's layer-1 partial sums."""
+        self.params_changed()
+        net = self._net or self.cnet()
+        _lib.check(self.lib.loc_train_step_chain(C.byref(net), _ptr(rows), int(n_b), int(t_off), _ptr(mask),
+                                                 _ptr(loss_out), _ptr(bn_next), _ptr(rows_next), int(n_b_next),
+                                                 1 if fwd_done else 0, ev0, ev1, _stream()), "loc_train_step_chain")
+
     def epoch_bn_stats(self, rows_all, batch, n_last, n_steps, stats_ep):
         """BN batch statistics of every minibatch of the epoch in one launch, the epoch's moving-statistics
         updates, and step 0's scale/shift (loc_bn_epoch_stats)."""

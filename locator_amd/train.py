@@ -64,7 +64,9 @@ class History:
 class EpochRunner:
     """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
 
-    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True):
+    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True, chain=None):
+        """chain: None = chain consecutive steps where the library supports it (LocatorNet.chain_supported), False =
+        one layer-1 forward launch per step (the unchained schedule; tests compare the two)."""
         self.slot_rows = net.set_batch(int(batch_size))      # validates 1..128 and the shape constraints
         self.net = net
         dev = net.device
@@ -90,6 +92,7 @@ class EpochRunner:
         self.epochs_run = 0
         self.step_sizes = np.array([min(self.batch, self.n_train - j * self.batch) for j in range(self.steps)])
         net.cnet()
+        self.chain = net.chain_supported() if chain is None else (bool(chain) and net.chain_supported())
 
     def enqueue(self, ev=None):
         net = self.net
@@ -100,6 +103,14 @@ class EpochRunner:
             mask = self.masks[j * self.mask_stride:] if self.masks is not None else None
             e0, e1 = (ev[j] if ev is not None else (None, None))
             nxt = self.stats_ep[(j + 1) * sz:] if j + 1 < self.steps else None
+            if self.chain:
+                # the epoch's minibatches are all known: step j's layer-1 backward also computes step j + 1's layer-1
+                # forward from the updated weights while they are in registers (one pass over W1 per step)
+                last = j + 1 >= self.steps
+                net.train_step_chain(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], nxt,
+                                     None if last else self.perm_dev[(j + 1) * self.batch:],
+                                     0 if last else int(self.step_sizes[j + 1]), j > 0, e0, e1)
+                continue
             net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
                            bn_ready=True, bn_next=nxt)
         if self.n_val:

@@ -1,0 +1,9 @@
+for a in "" 4 92; do
+  if [ -z "$a" ]; then L=""; else L="--lib locator_amd/liblocator_hip_chain$a.so"; fi
+  timeout 200 python bench.py --no-l1-gemm --steps 60 $L 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+r = d['roofline']
+print('ablate', '$a' or 0, 'step us', d['us_per_minibatch_step'], 'kernel us', round(623.95e6 / (r['achieved'] * 1e9) * 1e6, 1), 'samples/s', d['value'], 'loss', d['final_loss'], d['final_val_loss'])
+"
+done
