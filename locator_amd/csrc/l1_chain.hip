@@ -64,19 +64,18 @@ __device__ __forceinline__ void ch_gload8(uint32_t& v0, uint32_t& v1, const void
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     v0 = v.x; v1 = v.y;
 }
-// wait until at most N vector-memory operations are outstanding; the operands tie the registers the wait protects, so
-// no use of them can be scheduled above it
+// Wait until at most N vector-memory operations are outstanding; the operands tie the registers the wait protects, so
+// no use of them can be scheduled above it.  COUNTING RULE (gfx9 has one counter for loads and stores): loads retire in
+// order among loads and stores among stores, but a store may retire before an older load.  So "at most N outstanding"
+// proves that a load has landed only if N is the number of LOADS issued after it -- stores never count.
 template <int N>
-__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4]) {
-    asm volatile("s_waitcnt vmcnt(%12)"
+__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], uint32_t& s0, uint32_t& s1,
+                                             uint32_t& s2) {
+    asm volatile("s_waitcnt vmcnt(%15)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
-                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(s0), "+v"(s1), "+v"(s2)
                  : "n"(N)
                  : "memory");
-}
-template <int N>
-__device__ __forceinline__ void ch_wait_small(uint32_t& a, uint32_t& b, uint32_t& c) {
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 
 constexpr int CH_HP = 256, CH_PZ = CH_HP + 1, CH_TP = 33;
@@ -185,12 +184,11 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         const int G = gridDim.x, kt = blockIdx.x;
         if (kt < nkt) {
             fetch(kt);
-            ch_wait_small<0>(ld0, ld1, ld2);
+            ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
             stage(0);
         }
         if (kt + G < nkt) fetch(kt + G);                      // staged at the end of the first iteration
-        ch_wait_small<0>(ld0, ld1, ld2);
-        ch_wait_unit<0>(wA, mA, vA);
+        ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
     }
     __syncthreads();
 
@@ -214,8 +212,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 
     f32x16 facc = {0};
 
-    // Vector-memory operations of one iteration, in program order (hand-counted waits depend on it):
-    //   12 prefetch loads (kt_next >= 0) | 12 stores of this unit | 0..3 small loads of tile + 2 | barrier | 0..5 small stores
+    // Vector-memory operations of one iteration, in program order (the hand-counted wait depends on it):
+    //   12 prefetch loads (kt_next >= 0) | wait | 12 stores of this unit | 0..3 small loads of tile + 2 | barrier | 0..5 small stores
     auto step = [&](int kt, int kt_next, int kt_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
                     f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
         const int k = kt * KT + jl;
@@ -228,12 +226,13 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         float pv = smc[640 + lane], pm = smc[704 + lane], pvv = smc[768 + lane];
         float nmu = smc[832 + jl], nvar = smc[864 + jl];
         const u32x4 xr = *reinterpret_cast<const u32x4*>(smc + 256 + jl * 8 + 4 * hi);
-        // this unit's 12 loads are older than the previous iteration's 12 stores and the 12 loads just issued; on the last
-        // tile nothing is issued and everything is awaited.  ONE tied wait for both cases: two would meet in a phi and
-        // cost a copy of the whole register set
+        // ONE wait per iteration, right after the next unit's 12 loads: "at most 12 outstanding" proves every older load
+        // landed -- this unit (requested an iteration ago) and the next tile's small operands ld0..2 (requested at the end of
+        // the previous iteration).  On the last tile nothing is issued and everything is awaited.  One tied wait for both
+        // cases: two would meet in a phi and cost a copy of the whole register set.
         if (kt_next >= 0) load_unit(kt_next, wn, mn, vn);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ch_wait_unit<24>(wq, mq, vq);
+        ch_wait_unit<12>(wq, mq, vq, ld0, ld1, ld2);
 
         // dxhat tile of this wave's 32 units: D[i = row b][j = SNP], contraction over units h = w*32 + rowmap(s, hi)
         f32x16 dx = {0};
@@ -289,11 +288,9 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tw[jl * TP + rowmap(r, hi)] = wq[r >> 2][r & 3];   // T[SNP][unit]
         }
-        // The next tile's small operands, requested at the end of the previous iteration, go to the other LDS buffer: they
-        // are older than that iteration's small stores, this one's 12 prefetch loads and its 12 stores.  Then the request
-        // for the tile after next.
+        // The next tile's small operands (landed: see the wait above) go to the other LDS buffer, then the request for
+        // the tile after next.
         if (kt_next >= 0 && !(LOC_CHAIN_ABLATE & 2)) {
-            ch_wait_small<24>(ld0, ld1, ld2);
             stage(par ^ 1);
             if (kt_next2 >= 0) fetch(kt_next2);
         }
