@@ -52,7 +52,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (no sparsity)
 TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
-TRAFFIC_SOURCES = ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/common.h")
+TRAFFIC_SOURCES = ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/l1_chain.hip", "locator_amd/csrc/common.h")
 
 
 def l1_bwd_bytes(K, H, n_b):
@@ -60,6 +60,17 @@ def l1_bwd_bytes(K, H, n_b):
     (24 B/weight), the batch's uint8 genotype rows once, BN scale/shift/mean/rstd read (16 B/SNP),
     gamma,beta and their Adam moments read + written (48 B/SNP), dZ1 and b1 state."""
     return 24 * K * H + n_b * K + 64 * K + 4 * 32 * H + 24 * H
+
+
+def l1_chain_bytes(K, H, n_b, n_b_next, groups):
+    """The same for one l1_bwd_adam_chain launch (locator_amd/csrc/l1_chain.hip): the layer-1 backward's bytes, plus --
+    when the launch also computes the next minibatch's layer-1 forward -- that minibatch's genotype rows, its batch
+    statistics (8 B/SNP), the next step's [scale|shift|mean|rstd] written (16 B/SNP) and the partial sums
+    [groups][32][H] fp32.  W1, m, v still cross HBM exactly once each way."""
+    b = l1_bwd_bytes(K, H, n_b)
+    if n_b_next:
+        b += n_b_next * K + 8 * K + 16 * K + groups * 32 * H * 4
+    return b
 
 
 def step_bytes(K, H, n_b, L=10):
@@ -74,8 +85,8 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(K, H, n):
-    """PMC bytes per l1_bwd_adam launch from the committed profile, or (None, why) when it does not describe the
+def measured_traffic(K, H, n, kernel):
+    """PMC bytes per launch of `kernel` (name prefix) from the committed profile, or (None, why) when it does not describe the
     kernel that is running now."""
     path = os.path.join(ROOT, TRAFFIC_PROFILE)
     try:
@@ -86,7 +97,7 @@ def measured_traffic(K, H, n):
         return None, f"{TRAFFIC_PROFILE} is for another workload"
     if pm.get("kernel_sources_sha256_16") != kernel_sources_sha():
         return None, f"{TRAFFIC_PROFILE} was taken on other kernel sources (re-run tools/pmc_traffic.sh)"
-    key = [k for k in pm["kernels"] if k.startswith("l1_bwd_adam_kernel<%d" % ((H + 31) // 32))]
+    key = [k for k in pm["kernels"] if k.startswith(kernel)]
     if not key:
         return None, "kernel not in profile"
     return int(pm["kernels"][key[0]]["traffic_bytes"]), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, sources {pm['kernel_sources_sha256_16']})"
@@ -457,6 +468,7 @@ def main():
             _lib.check(lib.loc_event_create(C.byref(h)))
             evs.append(h)
         ms, by = [], []
+        chain_groups = max(1, min(f0.net.l1_bwd_grid // 2, f0.net.d.Kp // 32))     # api.hip: chain_grid_of
         for k in range(n_ep):
             pairs = [(evs[2 * (k * steps_per_epoch + j)], evs[2 * (k * steps_per_epoch + j) + 1])
                      for j in range(steps_per_epoch)]
@@ -466,13 +478,19 @@ def main():
                 o = C.c_float()
                 _lib.check(lib.loc_event_elapsed_ms(a, b, C.byref(o)))
                 ms.append(o.value)
-                by.append(l1_bwd_bytes(K, H, int(f0.runner.step_sizes[j])))
+                nb = int(f0.runner.step_sizes[j])
+                if f0.runner.chain:
+                    nb_next = int(f0.runner.step_sizes[j + 1]) if j + 1 < steps_per_epoch else 0
+                    by.append(l1_chain_bytes(K, H, nb, nb_next, chain_groups))
+                else:
+                    by.append(l1_bwd_bytes(K, H, nb))
         for h in evs:
             lib.loc_event_destroy(h)
         t_mean = float(np.mean(ms)) * 1e-3
         achieved = float(np.mean(by)) / t_mean / 1e9
-        traffic, traffic_source = measured_traffic(K, H, n)
-        roof = {"bound": "hbm", "kernel": "l1_bwd_adam_kernel", "achieved": round(achieved, 1),
+        kname = "l1_bwd_adam_chain_kernel" if f0.runner.chain else "l1_bwd_adam_kernel<%d" % ((H + 31) // 32)
+        traffic, traffic_source = measured_traffic(K, H, n, kname)
+        roof = {"bound": "hbm", "kernel": kname.split("<")[0], "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source, "bytes_per_launch": int(np.mean(by)),
                 "us_per_launch": round(t_mean * 1e6, 2), "launches_timed": len(ms)}

@@ -58,6 +58,22 @@ def test_chained_epochs_equal_unchained_epochs(K, nlayers, n_train, drop_p):
     assert err["mov_mean"] == 0.0 and err["mov_var"] == 0.0
 
 
+def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps():
+    """BASELINE.json's SNP count (100,000: 3,125 k-tiles, 12 or 13 per workgroup, every iteration of the hand-counted
+    pipeline in steady state under a saturated memory system), 160 training rows = 5 full minibatches, 2 epochs."""
+    K, width, nlayers, n_train = 100000, 256, 10, 160
+    x, y, p, rng = make_problem(n_train + 20, K, width, nlayers, seed=100)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
+    perms = [np.random.default_rng(70 + e).permutation(n_train) for e in range(2)]
+    _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, 0.25, True)
+    _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, 0.25, True)
+    assert maxerr(h0, h1) < 2e-5, (h0, h1)
+    err = params_err(p0, p1)
+    assert max(err.values()) < 5e-6, err
+    assert max(params_err(m0, m1).values()) < 1e-6
+    np.testing.assert_allclose(v1["W"][0], v0["W"][0], rtol=2e-3, atol=1e-12)
+
+
 def test_chained_epochs_match_the_oracle_fit():
     """Chained schedule against oracle.fit with the same permutations and the device's dropout masks: 4 epochs x 4
     steps (last minibatch of 4 rows) at width 256.  Tolerances of test_short_fit_trajectory_matches_oracle_fit."""

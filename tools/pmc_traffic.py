@@ -24,11 +24,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_sources_sha():
     """Same hash bench.py computes: `traffic` is only reported while the kernel sources still match the profile."""
     h = hashlib.sha256()
-    for rel in ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/common.h"):
+    for rel in ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/l1_chain.hip", "locator_amd/csrc/common.h"):
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     return h.hexdigest()[:16]
 
-WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer")
+WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_bwd_adam_chain_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer")
 
 
 def per_kernel(path, counter):
