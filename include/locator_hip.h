@@ -100,6 +100,9 @@ typedef struct loc_tuning {
     int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
+    int chain_tail;       /* chained steps (loc_train_step_chain): 0 = default: the step's hidden-layer / head Adam tail runs
+                             as trailing workgroups of the chained layer-1 launch (they fill the compute units that finish
+                             their k-tiles an iteration early); -1 = its own launch after it (measurement switch)          */
 } loc_tuning;
 
 /* Everything a training / inference step needs.  All device pointers. */

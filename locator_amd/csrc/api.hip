@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "common.h"
+#include "stack_tail.h"
 
 static thread_local char g_err[512] = "";
 
@@ -199,15 +200,26 @@ static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int
         if (chain) {
             // layer-1 backward + Adam (W1, b1, gamma, beta, the next step's scale/shift) and -- rows_next given -- the
             // next minibatch's layer-1 forward partial sums from the weights while they are in registers
-            TRY(loc_l1_backward_adam_chain(net->X, net->x_pitch, rows, n_b, rows_next, n_b_next, d, w.bn4, bn_next_stats,
-                                           dzl(1), P + lay.w1, M + lay.w1, V + lay.w1, P + lay.gamma, P + lay.beta,
-                                           M + lay.gamma, V + lay.gamma, M + lay.beta, V + lay.beta, P + lay.b1,
-                                           M + lay.b1, V + lay.b1, at, atl, net->lr, net->t_base, t_off,
-                                           chain_grid_of(net), w.partial, w.partial_floats, &net->tune, stream));
+            // ... and, unless tune.chain_tail says otherwise, the step's hidden-layer / head Adam tail as trailing
+            // workgroups of the same launch (it only needs what the stack kernel left in scratch)
+            const bool merged = net->tune.chain_tail >= 0;
+            loc_dw_tail_args ta;
+            ta.L = L; ta.n_pre = npre; ta.n_b = n_b; ta.use_drop = use_drop ? 1 : 0;
+            ta.acts = w.acts; ta.adrop = w.adrop; ta.dz = w.dz; ta.head_out = w.head_out;
+            ta.P = P; ta.M = M; ta.V = V; ta.WhT = net->wht;
+            ta.off_wh = lay.wh; ta.off_bh = lay.bh; ta.off_wa = lay.wa; ta.off_ba = lay.ba; ta.off_wb = lay.wb; ta.off_bb = lay.bb;
+            ta.loss_out = loss_out; ta.alpha_tab = at; ta.alpha_tab_len = atl; ta.lr = net->lr; ta.t_base = net->t_base;
+            ta.t_off = t_off; ta.slot_rows = slot;
+            TRY(l1_chain_launch(net->X, net->x_pitch, rows, n_b, rows_next, n_b_next, d, w.bn4, bn_next_stats, dzl(1),
+                                P + lay.w1, M + lay.w1, V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma,
+                                V + lay.gamma, M + lay.beta, V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, at, atl,
+                                net->lr, net->t_base, t_off, chain_grid_of(net), w.partial, w.partial_floats, &net->tune,
+                                merged ? &ta : nullptr, stream));
             if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
-            TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P, M,
-                                       V, net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at, atl,
-                                       net->lr, net->t_base, t_off, nullptr, stream));
+            if (!merged)
+                TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P,
+                                           M, V, net->wht, lay.wh, lay.bh, lay.wa, lay.ba, lay.wb, lay.bb, loss_out, at,
+                                           atl, net->lr, net->t_base, t_off, nullptr, stream));
             return 0;
         }
         TRY(loc_l1_backward_adam_main(net->X, net->x_pitch, rows, n_b, d, w.bn4, dzl(1), P + lay.w1, M + lay.w1,

@@ -22,6 +22,7 @@
 // Same arithmetic per weight as l1_bwd_adam_kernel (fp32 MFMA, Adam with v_rcp / v_sqrt); the gamma / beta gradient is
 // the sum of 8 per-wave partials instead of 2 per-range partials (a different, equally fixed summation order).
 #include "common.h"
+#include "stack_tail.h"
 
 #define KT 32
 
@@ -91,8 +92,18 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     float* __restrict__ m_gamma, float* __restrict__ v_gamma, float* __restrict__ m_beta, float* __restrict__ v_beta,
     float* __restrict__ b1, float* __restrict__ m_b1, float* __restrict__ v_b1, const float* __restrict__ alpha_tab,
     int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off,
-    float* __restrict__ partial_out) {
+    float* __restrict__ partial_out, int n_tail, loc_dw_tail_args ta) {
     constexpr int NHT = 8, Hp = CH_HP, PZ = CH_PZ, TP = CH_TP;
+    // Trailing workgroups (n_tail of them): the step's other Adam tail -- hidden-layer dW / db, heads, batch loss
+    // (stack_tail.h).  It depends on nothing this kernel writes.  Workgroups are dispatched in index order, so these start
+    // when the first layer-1 workgroups retire: 3125 k-tiles over 256 workgroups leave most compute units idle during the
+    // last iteration of the others, which is where this work goes instead of into a launch of its own.
+    const int G = (int)gridDim.x - n_tail;
+    if ((int)blockIdx.x >= G) {
+        loc_gb_tail none = {};
+        stack_dw_all_body<8, 1>((int)blockIdx.x - G, ta, none);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                                          // [32][PZ]   dZ of this step
     int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);        // [32]
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         }
     };
     {
-        const int G = gridDim.x, kt = blockIdx.x;
+        const int kt = blockIdx.x;
         if (kt < nkt) {
             fetch(kt);
             ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
@@ -339,7 +350,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // workgroup g owns k-tiles g, g + G, g + 2G, ...: at any moment the G workgroups stream one contiguous G * 32 KB
     // window of W1 / m / v, which spreads over every HBM channel
     {
-        const int G = gridDim.x;
         for (int kt = blockIdx.x; kt < nkt; kt += 2 * G) {
             auto nx = [&](int j) { return kt + j * G < nkt ? kt + j * G : -1; };
             step(kt, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
@@ -356,14 +366,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 
 extern "C" int loc_l1_chain_supported(int Hp) { return Hp == CH_HP; }
 
-extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
                                           const int32_t* rows_next, int n_b_next, const loc_dims* d, float* bn4,
                                           const float* bn_next_stats, const float* dz1, float* w1s, float* m1s,
                                           float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
                                           float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
                                           const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                           int t_off, int grid, float* partial, int64_t partial_floats,
-                                          const loc_tuning* tune, void* stream) {
+                                          const loc_tuning* tune, const loc_dw_tail_args* tail, void* stream) {
     if (d->Hp != CH_HP) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 256 (got %d)", d->Hp); return -1; }
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..32", n_b); return -1; }
     if (rows_next && (n_b_next < 1 || n_b_next > LOC_ROWS || !bn_next_stats)) {
@@ -375,6 +385,15 @@ extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, con
         loc_set_error("loc_l1_backward_adam_chain: genotype rows must be 16-byte aligned (pitch %lld)", (long long)x_pitch);
         return -1;
     }
+    if (beta != gamma + d->Kp || m_beta != m_gamma + d->Kp || v_beta != v_gamma + d->Kp) {
+        loc_set_error("loc_l1_backward_adam_chain: beta / m_beta / v_beta must sit Kp floats behind gamma / m_gamma / v_gamma "
+                      "(loc_param_layout)");
+        return -1;
+    }
+    if ((int64_t)d->Kp * 1024 >= ((int64_t)1 << 32)) {
+        loc_set_error("loc_l1_backward_adam_chain: more than 4M SNPs exceed the kernel's 32-bit byte offsets");
+        return -1;
+    }
     const int nkt = d->Kp / KT;
     if (grid < 1) grid = 1;
     if (grid > nkt) grid = nkt;
@@ -383,14 +402,22 @@ extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, con
         return -1;
     }
     const size_t lds = CH_LDS_FLOATS * sizeof(float);
+    // the step's hidden-layer / head Adam tail as trailing workgroups: (L - 1) * 64 weight tiles + the head block
+    loc_dw_tail_args ta = {};
+    int n_tail = 0;
+    if (tail) {
+        if (tail->n_b != n_b || tail->L < 2) { loc_set_error("loc_l1_backward_adam_chain: inconsistent tail arguments"); return -1; }
+        ta = *tail;
+        n_tail = (tail->L - 1) * 64 + 1;
+    }
     const int ntm = !tune || tune->l1b_nt_mask == 0 ? 13 : (tune->l1b_nt_mask < 0 ? 0 : tune->l1b_nt_mask);
 #define LAUNCH_CHAIN(M)                                                                                            \
     {                                                                                                              \
         LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M>), lds);                                                        \
-        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M>), dim3(grid), dim3(512), lds, (hipStream_t)stream, X, x_pitch, \
-                           rows, n_b, rows_next, n_b_next, d->K, d->Kp, bn4, bn_next_stats, dz1, w1s, m1s, v1s, gamma, \
-                           beta, m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr,   \
-                           t_base, t_off, partial);                                                                \
+        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M>), dim3(grid + n_tail), dim3(512), lds, (hipStream_t)stream, X, \
+                           x_pitch, rows, n_b, rows_next, n_b_next, d->K, d->Kp, bn4, bn_next_stats, dz1, w1s, m1s, v1s, \
+                           gamma, beta, m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, \
+                           t_base, t_off, partial, n_tail, ta);                                                    \
     }
     switch (ntm) {
         case 0: LAUNCH_CHAIN(0) break;
@@ -401,4 +428,17 @@ extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, con
 #undef LAUNCH_CHAIN
     LOC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
+                                          const int32_t* rows_next, int n_b_next, const loc_dims* d, float* bn4,
+                                          const float* bn_next_stats, const float* dz1, float* w1s, float* m1s,
+                                          float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma,
+                                          float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
+                                          const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
+                                          int t_off, int grid, float* partial, int64_t partial_floats,
+                                          const loc_tuning* tune, void* stream) {
+    return l1_chain_launch(X, x_pitch, rows, n_b, rows_next, n_b_next, d, bn4, bn_next_stats, dz1, w1s, m1s, v1s, gamma, beta,
+                           m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, t_base, t_off,
+                           grid, partial, partial_floats, tune, nullptr, stream);
 }

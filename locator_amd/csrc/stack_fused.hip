@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stack_tail.h"
 
 #define SF_THREADS 512
 
@@ -278,237 +279,10 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Everything that reduces over the batch rows, for all hidden layers at once.
-// Blocks [0, (L-1)*NHT^2): one 32x32 tile of W_l (l = 2..L): dW = in_l^T dz_l on the matrix core (wave 0),
-//   Adam by all 512 threads, and the transposed copy W_l^T refreshed through LDS.  Tile row 0 also does db.
-// Last block: heads (dWa, dba, dWb, dbb + Adam) and the batch loss.
-// ---------------------------------------------------------------------------------------------
+// Everything that reduces over the batch rows, for all hidden layers at once: see stack_tail.h (stack_dw_all_body).
 template <int NHT, int RB>
-__global__ __launch_bounds__(512) void stack_dw_all_kernel(
-    int L, int n_pre, int n_b, int use_drop, const float* __restrict__ acts, const float* __restrict__ adrop,
-    const float* __restrict__ dz, const float* __restrict__ head_out, float* __restrict__ P, float* __restrict__ M,
-    float* __restrict__ V, float* __restrict__ WhT, int64_t off_wh, int64_t off_bh, int64_t off_wa, int64_t off_ba,
-    int64_t off_wb, int64_t off_bb, float* __restrict__ loss_out, const float* __restrict__ alpha_tab,
-    int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off, loc_gb_tail gb,
-    int slot_rows) {
-    constexpr int Hp = NHT * 32;
-    // Blocks past the tiles and the heads (only when gb.K > 0): BatchNorm gamma/beta Adam for 512 SNPs each,
-    // from the partial sums the layer-1 backward left -- the step's two row-reducing tails share one launch.
-    if ((int)blockIdx.x > (L - 1) * NHT * NHT) {
-        const int k = ((int)blockIdx.x - (L - 1) * NHT * NHT - 1) * 512 + (int)threadIdx.x;
-        if (k < gb.K)
-            gamma_beta_adam_body(k, gb.Kp, gb.gbs, gb.gamma, gb.beta, gb.m_gamma, gb.v_gamma, gb.m_beta, gb.v_beta,
-                                 adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off), gb.next_stats, gb.bn4);
-        return;
-    }
-    // RB = 0: the number of 32-row blocks is a run-time value (--batch_size > 128): wave w takes blocks w, w + 8, ...
-    constexpr int NP = RB == 0 ? 8 : (RB > 1 ? RB : 1);
-    __shared__ float gt[32][33];
-    __shared__ float gtp[NP][32][33];                   // per-row-block (RB = 0: per-wave) partial tiles
-    __shared__ float sbp[NP][32];
-    __shared__ float hsm[RB == 0 ? 1 : 32 * RB][8];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
-    const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;
-    const int nrb = RB == 0 ? (n_b + 31) / 32 : RB;    // 32-row blocks in use (1 unless --batch_size > 32)
-    const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
-    const int n_tiles = (L - 1) * NHT * NHT;
-
-    if ((int)blockIdx.x < n_tiles) {
-        const int li = blockIdx.x / (NHT * NHT);          // 0-based hidden index: layer l = li + 2
-        const int tile = blockIdx.x % (NHT * NHT);
-        const int kt = tile / NHT, nt = tile % NHT;
-        const int l = li + 2;
-        const float* in2 = (use_drop && l - 1 == n_pre) ? adrop : acts + (int64_t)(l - 2) * blk;
-        const float* dz2 = dz + (int64_t)(l - 1) * blk;
-        float* W2 = P + off_wh + li * HH;
-        float* mW2 = M + off_wh + li * HH;
-        float* vW2 = V + off_wh + li * HH;
-        float* WT2 = WhT + li * HH;
-        int64_t idx[2];
-        float wv[2], mv[2], vv[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = t + 512 * i;
-            idx[i] = (int64_t)(kt * 32 + (e >> 5)) * Hp + nt * 32 + (e & 31);
-            wv[i] = W2[idx[i]]; mv[i] = mW2[idx[i]]; vv[i] = vW2[idx[i]];
-        }
-        if constexpr (RB == 1) {
-            if (w == 0) {
-                float av[16], bv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int b = 2 * s + hi;
-                    av[s] = in2[b * Hp + kt * 32 + jl];
-                    bv[s] = dz2[b * Hp + nt * 32 + jl];
-                }
-                f32x16 g = {0};
-#pragma unroll
-                for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gt[rowmap(r, hi)][jl] = g[r];
-                if (kt == 0) {
-                    float sb = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sb += bv[i];
-                    sb += __shfl_xor(sb, 32);
-                    if (hi == 0) {
-                        const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + jl;
-                        float bw = P[o], bm = M[o], bvv = V[o];
-                        adam_update(bw, bm, bvv, sb, alpha);
-                        P[o] = bw; M[o] = bm; V[o] = bvv;
-                    }
-                }
-            }
-        } else if constexpr (RB == 0) {
-            // run-time block count: wave w accumulates blocks w, w + 8, ... in order; the 8 per-wave tiles are then
-            // added in a fixed order
-            {
-                f32x16 g = {0};
-                float sb = 0.f;
-                for (int rb = w; rb < nrb; rb += 8) {
-                    float av[16], bv[16];
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const int b = 32 * rb + 2 * s + hi;
-                        av[s] = in2[(int64_t)b * Hp + kt * 32 + jl];
-                        bv[s] = dz2[(int64_t)b * Hp + nt * 32 + jl];
-                    }
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sb += bv[i];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gtp[w][rowmap(r, hi)][jl] = g[r];
-                sb += __shfl_xor(sb, 32);
-                if (hi == 0) sbp[w][jl] = sb;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = t + 512 * i;
-                float a = gtp[0][e >> 5][e & 31];
-#pragma unroll
-                for (int rb = 1; rb < 8; ++rb) a += gtp[rb][e >> 5][e & 31];
-                gt[e >> 5][e & 31] = a;
-            }
-            if (kt == 0 && t < 32) {
-                float sb = sbp[0][t];
-#pragma unroll
-                for (int rb = 1; rb < 8; ++rb) sb += sbp[rb][t];
-                const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + t;
-                float bw = P[o], bm = M[o], bvv = V[o];
-                adam_update(bw, bm, bvv, sb, alpha);
-                P[o] = bw; M[o] = bm; V[o] = bvv;
-            }
-        } else {
-            // one wave per row block (their load latencies overlap); the RB partial tiles are added in a fixed order
-            if (w < RB) {
-                float av[16], bv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int b = 32 * w + 2 * s + hi;
-                    av[s] = in2[b * Hp + kt * 32 + jl];
-                    bv[s] = dz2[b * Hp + nt * 32 + jl];
-                }
-                f32x16 g = {0};
-#pragma unroll
-                for (int s = 0; s < 16; ++s) g = mfma32(av[s], bv[s], g);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gtp[w][rowmap(r, hi)][jl] = g[r];
-                float sb = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sb += bv[i];
-                sb += __shfl_xor(sb, 32);
-                if (hi == 0) sbp[w][jl] = sb;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = t + 512 * i;
-                float a = gtp[0][e >> 5][e & 31];
-#pragma unroll
-                for (int rb = 1; rb < RB; ++rb) a += gtp[rb][e >> 5][e & 31];
-                gt[e >> 5][e & 31] = a;
-            }
-            if (kt == 0 && t < 32) {
-                float sb = sbp[0][t];
-#pragma unroll
-                for (int rb = 1; rb < RB; ++rb) sb += sbp[rb][t];
-                const int64_t o = off_bh + (int64_t)li * Hp + nt * 32 + t;
-                float bw = P[o], bm = M[o], bvv = V[o];
-                adam_update(bw, bm, bvv, sb, alpha);
-                P[o] = bw; M[o] = bm; V[o] = bvv;
-            }
-        }
-        __syncthreads();
-        float nw[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = t + 512 * i;
-            adam_update(wv[i], mv[i], vv[i], gt[e >> 5][e & 31], alpha);
-            W2[idx[i]] = wv[i]; mW2[idx[i]] = mv[i]; vW2[idx[i]] = vv[i];
-            nw[i] = wv[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int e = t + 512 * i; gt[e >> 5][e & 31] = nw[i]; }   // [k][n]
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {      // W^T[n][k], coalesced along k
-            const int e = t + 512 * i, n = e >> 5, k = e & 31;
-            WT2[(int64_t)(nt * 32 + n) * Hp + kt * 32 + k] = gt[k][n];
-        }
-        return;
-    }
-    // ---- head block
-    const int nrow = 32 * nrb;
-    if constexpr (RB != 0) {
-        for (int i = t; i < 8 * nrow; i += 512) hsm[i >> 3][i & 7] = head_out[i];
-        __syncthreads();
-    }
-    // head_out[b][0..7] = {per-sample loss, dy1[0..1], y1[0..1], dy2[0..1], -}: from LDS, or (run-time block count) from L2
-    auto H = [&](int b, int c) -> float { return RB != 0 ? hsm[b][c] : head_out[(int64_t)b * 8 + c]; };
-    const float* aL = acts + (int64_t)(L - 1) * blk;
-    if (t == 0) {
-        float s = 0.f;
-        for (int b = 0; b < n_b; ++b) s += H(b, 0);
-        loss_out[0] = s / (float)n_b;
-    }
-    if (t >= 64 && t < 72) {
-        const int q = t - 64;
-        float g = 0.f;
-        int64_t off;
-        if (q < 4) {            // dWb[i][j] = sum_b y1[b][i] dy2[b][j]
-            const int i = q >> 1, j = q & 1;
-            for (int b = 0; b < nrow; ++b) g += H(b, 3 + i) * H(b, 5 + j);
-            off = off_wb + q;
-        } else if (q < 6) {     // dbb[j] = sum_b dy2[b][j]
-            for (int b = 0; b < nrow; ++b) g += H(b, 5 + (q - 4));
-            off = off_bb + (q - 4);
-        } else {                // dba[c] = sum_b dy1[b][c]
-            for (int b = 0; b < nrow; ++b) g += H(b, 1 + (q - 6));
-            off = off_ba + (q - 6);
-        }
-        float wv = P[off], mv = M[off], vv = V[off];
-        adam_update(wv, mv, vv, g, alpha);
-        P[off] = wv; M[off] = mv; V[off] = vv;
-    }
-    for (int k = t; k < Hp; k += 512) {      // dWa[k][c] = sum_b a_L[b][k] dy1[b][c]
-        float g0 = 0.f, g1 = 0.f;
-#pragma unroll 8
-        for (int b = 0; b < nrow; ++b) {
-            const float av = aL[(int64_t)b * Hp + k];
-            g0 = fmaf(av, H(b, 1), g0);
-            g1 = fmaf(av, H(b, 2), g1);
-        }
-        const int64_t o = off_wa + 2 * k;
-        float w0 = P[o], m0 = M[o], v0 = V[o], w1 = P[o + 1], m1 = M[o + 1], v1 = V[o + 1];
-        adam_update(w0, m0, v0, g0, alpha);
-        adam_update(w1, m1, v1, g1, alpha);
-        P[o] = w0; M[o] = m0; V[o] = v0; P[o + 1] = w1; M[o + 1] = m1; V[o + 1] = v1;
-    }
+__global__ __launch_bounds__(512) void stack_dw_all_kernel(loc_dw_tail_args ta, loc_gb_tail gb) {
+    stack_dw_all_body<NHT, RB>((int)blockIdx.x, ta, gb);
 }
 
 // hidden kernels -> transposed copies (after init / import / best-weight reload)
@@ -624,10 +398,15 @@ extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slo
     loc_gb_tail g;
     if (gb) g = *gb; else { g = loc_gb_tail{}; g.K = 0; }
     const int grid = (L - 1) * nht * nht + 1 + (g.K > 0 ? (g.K + 511) / 512 : 0);
-#define LAUNCH_RB(N, R)                                                                                           \
-    hipLaunchKernelGGL((stack_dw_all_kernel<N, R>), dim3(grid), dim3(512), 0, (hipStream_t)stream, L, n_pre, n_b, \
-                       use_drop, acts, adrop, dz, head_out, params, adam_m, adam_v, WhT, off_wh, off_bh, off_wa,   \
-                       off_ba, off_wb, off_bb, loss_out, alpha_tab, alpha_tab_len, lr, t_base, t_off, g, slot_rows);
+    loc_dw_tail_args ta;
+    ta.L = L; ta.n_pre = n_pre; ta.n_b = n_b; ta.use_drop = use_drop;
+    ta.acts = acts; ta.adrop = adrop; ta.dz = dz; ta.head_out = head_out;
+    ta.P = params; ta.M = adam_m; ta.V = adam_v; ta.WhT = WhT;
+    ta.off_wh = off_wh; ta.off_bh = off_bh; ta.off_wa = off_wa; ta.off_ba = off_ba; ta.off_wb = off_wb; ta.off_bb = off_bb;
+    ta.loss_out = loss_out; ta.alpha_tab = alpha_tab; ta.alpha_tab_len = alpha_tab_len; ta.lr = lr; ta.t_base = t_base;
+    ta.t_off = t_off; ta.slot_rows = slot_rows;
+#define LAUNCH_RB(N, R) \
+    hipLaunchKernelGGL((stack_dw_all_kernel<N, R>), dim3(grid), dim3(512), 0, (hipStream_t)stream, ta, g);
 #define LAUNCH(N)                                                                                                 \
     switch ((n_b + 31) / 32) {                                                                                    \
         case 1: LAUNCH_RB(N, 1) break;                                                                            \
