@@ -27,8 +27,8 @@
 #define KT 32
 
 // timing ablations (make ablate_chain A=<bits>): results are WRONG with any bit set; they only answer "what does this
-// part of the loop cost".  1 = no barrier, 2 = no per-tile small global loads, 4 = no next-forward part, 8 = no dxhat MFMAs,
-// 16 = no Adam arithmetic, 32 = no weight stores, 64 = no dW MFMAs
+// part of the loop cost".  1 = no barrier, 2 = no per-tile small operands, 4 = no next-forward part, 16 = no Adam
+// arithmetic, 32 = no weight stores
 #ifndef LOC_CHAIN_ABLATE
 #define LOC_CHAIN_ABLATE 0
 #endif
@@ -144,6 +144,19 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     }
     __syncthreads();
 
+    // dzsum[h] = sum_b dZ[b][h] for this lane's 16 units h = w*32 + rowmap(r, hi): column sums through `red` (free until
+    // the loop; the barriers below separate the two uses), then registers for the whole kernel
+    if (t < Hp) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) sum += dzl[b * PZ + t];
+        red[t] = sum;
+    }
+    __syncthreads();
+    float dzs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dzs[r] = red[w * 32 + rowmap(r, hi)];
+
     // gamma (lanes 0..31) or beta (lanes 32..63) of SNP jl of the tile: one Adam per lane.  beta / m_beta / v_beta sit Kp
     // floats behind gamma / m_gamma / v_gamma (loc_param_layout; checked by the launcher): one wave-uniform base each
     const int gbo = hi * Kp;
@@ -233,7 +246,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         const uint8_t* xt = reinterpret_cast<const uint8_t*>(smc);
         const u32x4 xp = *reinterpret_cast<const u32x4*>(xt + jl * 32 + hi * 16);      // 16 rows of SNP jl, packed
         auto xv = [&](int r) { return (float)((xp[r >> 2] >> (8 * (r & 3))) & 255u); };
-        const float sc = smc[512 + jl], sh = smc[544 + jl], mu = smc[576 + jl], rs = smc[608 + jl];
+        const float mu = smc[576 + jl], rs = smc[608 + jl];
+        const float gam = smc[640 + jl], bet = smc[672 + jl];          // gamma_k, beta_k before this step's update
         float pv = smc[640 + lane], pm = smc[704 + lane], pvv = smc[768 + lane];
         float nmu = smc[832 + jl], nvar = smc[864 + jl];
         const u32x4 xr = *reinterpret_cast<const u32x4*>(smc + 256 + jl * 8 + 4 * hi);
@@ -245,33 +259,28 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ch_wait_unit<12>(wq, mq, vq, ld0, ld1, ld2);
 
-        // dxhat tile of this wave's 32 units: D[i = row b][j = SNP], contraction over units h = w*32 + rowmap(s, hi)
-        f32x16 dx = {0};
-#if !(LOC_CHAIN_ABLATE & 8)
+        // ONE fp32 MFMA chain per unit:  Gn[h][k] = sum_b dZ[b][h] xn[b][k]  (D[i = unit][j = SNP], contraction over the
+        // batch rows b = rowmap(s, hi); xn = (x - mean) * rstd).  Everything else follows from it without forming dxhat
+        // (rows beyond the minibatch need no mask: their dZ rows are zero and the bytes staged for them are finite):
+        //   dW^T[h][k]          = sum_b dZ[b][h] (gamma_k xn[b][k] + beta_k)        = gamma_k Gn[h][k] + beta_k dzsum[h]
+        //   sum_b dxhat[b][k] xn[b][k] = sum_b sum_h dZ[b][h] W[h][k] xn[b][k]      = sum_h W[h][k] Gn[h][k]
+        //   sum_b dxhat[b][k]          = sum_h W[h][k] dzsum[h]                      (this wave's 32 units; old W)
+        f32x16 g = {0};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dx = mfma32(dzl[jl * PZ + w * 32 + rowmap(s, hi)], wq[s >> 2][s & 3], dx);
-#endif
+        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + w * 32 + jl], (xv(s) - mu) * rs, g);
         {
             float pg = 0.f, pb = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // rows beyond the minibatch need no mask here or in dW below: their dZ rows are zero (so is dxhat), and the
-                // genotype bytes staged for them (row 0's) are finite
-                const float xn = (xv(r) - mu) * rs;
-                pg = fmaf(dx[r], xn, pg);
-                pb += dx[r];
+                pg = fmaf(wq[r >> 2][r & 3], g[r], pg);
+                pb = fmaf(wq[r >> 2][r & 3], dzs[r], pb);
             }
             pg += __shfl_xor(pg, 32);
             pb += __shfl_xor(pb, 32);
             red[(par * 8 + w) * 64 + lane] = hi ? pb : pg;
         }
-        // dW^T tile: D[i = unit][j = SNP], contraction over batch rows b = rowmap(s, hi)
-        f32x16 g = {0};
 #pragma unroll
-        for (int s = 0; s < ((LOC_CHAIN_ABLATE & 64) ? 1 : 16); ++s) {
-            const float xh = fmaf(xv(s), sc, sh);
-            g = mfma32(dzl[rowmap(s, hi) * PZ + w * 32 + jl], xh, g);
-        }
+        for (int r = 0; r < 16; ++r) g[r] = fmaf(gam, g[r], bet * dzs[r]);
         // Adam on the weight tile, stores, and the tile's transpose for the next forward
         const uint32_t so = unit_off(kt);
         auto adam4 = [&](int q) {

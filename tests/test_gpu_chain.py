@@ -16,6 +16,31 @@ def _sync():
     torch.cuda.synchronize()
 
 
+def _assert_same_fit(p0, p1, m0, m1, v0, v1):
+    """Two fp32 evaluations of the same steps (chained / unchained schedule).  They differ in summation order (the
+    gamma / beta gradient: 8 per-wave partials against 2; the layer-1 partial sums) and in how dW1 and the gamma / beta
+    gradients are associated (the chained kernel derives them from sum_b dZ xn, l1_chain.hip), i.e. by fp32 round-off in
+    the gradients.  An entry whose gradient sits at Adam's eps scale moves by a fraction of lr = 1e-3 per step in a
+    direction round-off decides, so: the worst entry within 5 % of one Adam step, all but 0.1 % of the entries of the big
+    tensors within 2e-6, first moments 1e-5 (2e-6 for W1), second moments rtol 2e-3.  Measured against the fp64 oracle at
+    100,000 SNPs after 10 steps (tools/scratch/chain_vs_oracle.py): gamma max error 2.4e-5 unchained, 2.2e-6 chained -- the
+    chained kernel's association is the more accurate of the two."""
+    err = params_err(p0, p1)
+    assert max(err.values()) < 5e-5, err
+    for a, b in ((p0["W"][0], p1["W"][0]), (p0["gamma"], p1["gamma"]), (p0["beta"], p1["beta"])):
+        assert np.mean(np.abs(a.astype(np.float64) - b) > 2e-6) < 1e-3
+    for l in range(1, len(p0["W"])):
+        assert maxerr(p0["W"][l], p1["W"][l]) < 5e-6, (l, err)
+    merr = params_err(m0, m1)
+    assert max(merr.values()) < 1e-5 and merr["W0"] < 2e-6, merr
+    for l in range(len(v0["W"])):
+        np.testing.assert_allclose(v1["W"][l], v0["W"][l], rtol=2e-3, atol=1e-12)
+    np.testing.assert_allclose(v1["gamma"], v0["gamma"], rtol=2e-3, atol=1e-12)
+    np.testing.assert_allclose(v1["beta"], v0["beta"], rtol=2e-3, atol=1e-12)
+    # the moving statistics do not depend on the schedule at all
+    assert err["mov_mean"] == 0.0 and err["mov_var"] == 0.0
+
+
 def _run_epochs(x, y, p, tr, va, perms, chain, drop_p, use_graph, seed=5):
     from locator_amd.train import EpochRunner
     net = build_net(x, y, p, drop_p=drop_p, seed=seed)
@@ -44,18 +69,8 @@ def test_chained_epochs_equal_unchained_epochs(K, nlayers, n_train, drop_p):
     perms = [np.random.default_rng(7 + e).permutation(n_train) for e in range(3)]
     _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, drop_p, True)
     _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, drop_p, True)
-    # losses: 3 epochs x (train, val).  Everything is fp32; the two schedules differ in the order of the gamma / beta
-    # gradient sum (8 per-wave partials against 2) and of the layer-1 partial sums
-    assert maxerr(h0, h1) < 2e-5, (h0, h1)
-    err = params_err(p0, p1)
-    assert max(err.values()) < 5e-6, err
-    assert max(params_err(m0, m1).values()) < 1e-6
-    for l in range(len(v0["W"])):
-        np.testing.assert_allclose(v1["W"][l], v0["W"][l], rtol=2e-3, atol=1e-12)
-    np.testing.assert_allclose(v1["gamma"], v0["gamma"], rtol=2e-3, atol=1e-12)
-    np.testing.assert_allclose(v1["beta"], v0["beta"], rtol=2e-3, atol=1e-12)
-    # padded SNPs: gamma / beta / W1 rows beyond K do not exist in the export; the moving statistics are untouched by the chain
-    assert err["mov_mean"] == 0.0 and err["mov_var"] == 0.0
+    assert maxerr(h0, h1) < 2e-5, (h0, h1)          # 3 epochs x (train loss, validation loss)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
 
 
 def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps():
@@ -68,10 +83,7 @@ def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps():
     _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, 0.25, True)
     _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, 0.25, True)
     assert maxerr(h0, h1) < 2e-5, (h0, h1)
-    err = params_err(p0, p1)
-    assert max(err.values()) < 5e-6, err
-    assert max(params_err(m0, m1).values()) < 1e-6
-    np.testing.assert_allclose(v1["W"][0], v0["W"][0], rtol=2e-3, atol=1e-12)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
 
 
 def test_chained_epochs_match_the_oracle_fit():
