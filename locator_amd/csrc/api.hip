@@ -126,7 +126,8 @@ extern "C" int loc_train_chain_supported(const loc_net* net) {
     const loc_dims* d = &net->d;
     const bool in_drop = net->drop_p > 0.f && d->n_pre == 0;
     return d->L >= 2 && net->wht && loc_stack_fused_supported(d->Hp) && loc_l1_chain_supported(d->Hp) &&
-           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_grid_of(net) <= LOC_MAX_FWD_GRID;
+           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_grid_of(net) <= LOC_MAX_FWD_GRID &&
+           (int64_t)d->Kp * 1024 < ((int64_t)1 << 32) && (net->x_pitch % 16) == 0;
 }
 
 static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,

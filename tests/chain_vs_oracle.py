@@ -1,3 +1,6 @@
+"""Measurement helper (GPU): chained and unchained schedules of the same 10 steps at 100,000 SNPs, each against the fp64
+oracle fit -- which of the two fp32 associations of the gamma / beta / dW1 gradients is closer.
+  python tests/chain_vs_oracle.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from oracle import locator_oracle as O

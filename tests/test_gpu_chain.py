@@ -23,7 +23,7 @@ def _assert_same_fit(p0, p1, m0, m1, v0, v1):
     the gradients.  An entry whose gradient sits at Adam's eps scale moves by a fraction of lr = 1e-3 per step in a
     direction round-off decides, so: the worst entry within 5 % of one Adam step, all but 0.1 % of the entries of the big
     tensors within 2e-6, first moments 1e-5 (2e-6 for W1), second moments rtol 2e-3.  Measured against the fp64 oracle at
-    100,000 SNPs after 10 steps (tools/scratch/chain_vs_oracle.py): gamma max error 2.4e-5 unchained, 2.2e-6 chained -- the
+    100,000 SNPs after 10 steps (tests/chain_vs_oracle.py): gamma max error 2.4e-5 unchained, 2.2e-6 chained -- the
     chained kernel's association is the more accurate of the two."""
     err = params_err(p0, p1)
     assert max(err.values()) < 5e-5, err
