@@ -62,7 +62,7 @@ def l1_bwd_bytes(K, H, n_b):
     return 24 * K * H + n_b * K + 64 * K + 4 * 32 * H + 24 * H
 
 
-def l1_chain_bytes(K, H, n_b, n_b_next, groups):
+def l1_chain_bytes(K, H, n_b, n_b_next, groups, tail_layers=0):
     """The same for one l1_bwd_adam_chain launch (locator_amd/csrc/l1_chain.hip): the layer-1 backward's bytes, plus --
     when the launch also computes the next minibatch's layer-1 forward -- that minibatch's genotype rows, its batch
     statistics (8 B/SNP), the next step's [scale|shift|mean|rstd] written (16 B/SNP) and the partial sums
@@ -70,6 +70,10 @@ def l1_chain_bytes(K, H, n_b, n_b_next, groups):
     b = l1_bwd_bytes(K, H, n_b)
     if n_b_next:
         b += n_b_next * K + 8 * K + 16 * K + groups * 32 * H * 4
+    if tail_layers:
+        # the step's hidden-layer / head Adam tail riding as trailing workgroups of the launch: W, m, v of the hidden
+        # kernels read + written (24 B / weight) and the transposed copy written (4 B / weight)
+        b += 28 * ((tail_layers - 1) * H * H + (tail_layers + 1) * H + 8)
     return b
 
 
@@ -485,7 +489,7 @@ def main():
                 nb = int(f0.runner.step_sizes[j])
                 if f0.runner.chain:
                     nb_next = int(f0.runner.step_sizes[j + 1]) if j + 1 < steps_per_epoch else 0
-                    by.append(l1_chain_bytes(K, H, nb, nb_next, chain_groups))
+                    by.append(l1_chain_bytes(K, H, nb, nb_next, chain_groups, 0 if args.separate_tail else 10))
                 else:
                     by.append(l1_bwd_bytes(K, H, nb))
         for h in evs:
