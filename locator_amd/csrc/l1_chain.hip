@@ -9,18 +9,22 @@
 // disappears for every step but the first of an epoch.
 //
 // What makes that legal: xhat_{t+1}[b][k] = gamma'_k * (x - mu_k) * rstd_k + beta'_k needs the gamma / beta that step t
-// itself updates, and their gradients reduce over ALL units of SNP k.  So one workgroup owns whole k-tiles: wave w
-// (of 8) streams unit tile w of every k-tile of the workgroup's range,
-//     dW^T[h][k]   = sum_b dZ[b][h] xhat[b][k]            (A = dZ from LDS, B = xhat registers)      -> Adam on W, m, v
-//     dxhat[b][k]  = sum_h dZ[b][h] W[h][k]  (this wave's 32 units) -> (sum_b dxhat*xn, sum_b dxhat) per SNP -> LDS
+// itself updates, and their gradients reduce over ALL units of SNP k.  So one workgroup owns whole k-tiles (g, g + G,
+// g + 2G, ...: at any moment the G workgroups stream one contiguous window of W1 / m / v); wave w (of 8) streams unit
+// tile w of each, per k-tile:
+//     Gn[h][k]     = sum_b dZ[b][h] xn[b][k]        ONE fp32 MFMA chain (A = dZ from LDS, B = xn = (x - mean) * rstd)
+//     dW^T[h][k]   = gamma_k Gn[h][k] + beta_k sum_b dZ[b][h]                                -> Adam on W, m, v, 16-byte stores
+//     (sum_b dxhat xn, sum_b dxhat)[k] = (sum_h W[h][k] Gn[h][k], sum_h W[h][k] sum_b dZ[b][h])   this wave's 32 units -> LDS
 //     --- one LDS-only barrier per k-tile (the weight prefetch stays in flight across it) ---
 //     every wave adds the 8 partial sums in wave order, applies Adam to gamma_k / beta_k (wave 0 stores them and the
 //     next step's [scale|shift|mean|rstd]), builds xhat_{t+1} for the tile, and contracts it with its W' tile:
 //     z_{t+1}[b][h] += sum_k xhat_{t+1}[b][k] W'[k][h]   (A = xhat_{t+1}, lane = row; B = W' through a 4 KB per-wave
 //     LDS transpose: the accumulator layout has lane = SNP, the B operand needs lane = unit)
 // and the workgroup leaves partial[g][32][256] for l1_reduce_kernel, exactly like l1_fwd_partial_kernel.
-// Same arithmetic per weight as l1_bwd_adam_kernel (fp32 MFMA, Adam with v_rcp / v_sqrt); the gamma / beta gradient is
-// the sum of 8 per-wave partials instead of 2 per-range partials (a different, equally fixed summation order).
+// Adam per weight as in l1_bwd_adam_kernel (v_rcp / v_sqrt).  dW1 and the gamma / beta gradient are associated differently
+// from that kernel (which forms sum_b dZ xhat and dxhat = dZ W^T with two MFMA chains): same sums, fp32 round-off differs;
+// against the fp64 oracle this association is the closer one (tests/chain_vs_oracle.py).
+// Trailing workgroups of the launch run the step's hidden-layer / head Adam tail (stack_tail.h).
 #include "common.h"
 #include "stack_tail.h"
 
