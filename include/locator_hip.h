@@ -390,7 +390,11 @@ int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, 
  * of running the layer-1 forward.  The epoch-level BN statistics are required (bn_ready is implied; bn_next_stats as in
  * loc_train_step, mandatory with rows_next).  rows_next NULL = last step of the epoch.  Results equal loc_train_step's
  * up to the summation order of the BatchNorm gamma / beta gradient and of the layer-1 partial sums.
- * loc_train_chain_supported: width padding to 256, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output. */
+ * loc_train_chain_supported: width padding to 256, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output.
+ * CONTRACT: a step with fwd_done != 0 must directly follow, on the same stream, a chained step whose rows_next /
+ * n_b_next / bn_next_stats described it -- the hand-over lives in the workspace (layer-1 partial sums, scale/shift), so
+ * nothing that uses net->ws (loc_predict, loc_train_step, loc_bn_epoch_stats) may run in between.  The library cannot
+ * check this. */
 int loc_train_chain_supported(const loc_net* net);
 int loc_train_step_chain(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
                          float* loss_out, const float* bn_next_stats, const int32_t* rows_next, int n_b_next,
