@@ -367,7 +367,10 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
                                                                  const unsigned char* __restrict__ tiles,
                                                                  const float* __restrict__ delta,
                                                                  float* __restrict__ partial, int G, int n_mt, int npairs) {
-    constexpr int NB = UT == 1 ? 12 : 32;
+#ifndef G8_NB_UT1
+#define G8_NB_UT1 12       // digit fragments in flight per wave, 8-wave form (4 / 6 / 8 / 12: same time; 16 spills)
+#endif
+    constexpr int NB = UT == 1 ? G8_NB_UT1 : 32;
     constexpr int WU = 32 * UT;                             // units per wave
     extern __shared__ __attribute__((aligned(1024))) unsigned char g8_smem[];
     const int t = threadIdx.x, lane = t & 63;
