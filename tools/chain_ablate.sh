@@ -7,6 +7,6 @@ for a in "" 1 2 4 16 32; do
 import sys, json
 d = json.loads(sys.stdin.read())
 r = d['roofline']
-print('ablate', '$a' or 0, 'step us', d['us_per_minibatch_step'], 'kernel us', round(623.95e6 / (r['achieved'] * 1e9) * 1e6, 1), 'samples/s', d['value'], 'loss', d['final_loss'], d['final_val_loss'])
+print('ablate', '$a' or 0, 'step us', d['us_per_minibatch_step'], 'kernel us', r['us_per_launch'], 'samples/s', d['value'], 'loss', d['final_loss'], d['final_val_loss'])
 "
 done

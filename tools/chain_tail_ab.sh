@@ -1,3 +1,4 @@
+# Chained step with its Adam tail merged into the layer-1 launch (default) against a separate tail launch, on the GPU box
 for f in "" "--separate-tail"; do
   timeout 200 python bench.py --no-l1-gemm --no-cpu-baseline --steps 60 $f 2>/dev/null | tail -1 | python -c "
 import sys, json
