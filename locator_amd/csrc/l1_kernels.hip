@@ -331,8 +331,11 @@ __global__ __launch_bounds__(256) void l1_reduce_kernel(const float* __restrict_
 //
 // Work unit = one (k-tile, unit-tile) pair = 1024 weights = three contiguous 4 KB runs (W, m, v) in
 // the swizzled layout.  The units, ordered k-tile major, are cut into one contiguous range per WAVE;
-// a wave streams its range with 16-byte loads straight into the MFMA accumulator layout, prefetching
-// the next unit's 12 KB into a second register set while it works on the current one:
+// a wave streams its range with 16-byte loads straight into the MFMA accumulator layout, requesting
+// the next unit's 12 KB into a second register set before it works on the current one (round 3 found that the
+// compiler's wait counts, merged conservatively around the loop, make the first use of the CURRENT set wait for most
+// of that request, so little overlaps inside a wave; the kernel is HBM-bound through its 8 waves per CU regardless --
+// l1_chain.hip, which needed the overlap, uses untracked loads and a hand-counted wait instead):
 //     dW^T[h][k]  = sum_b dZ[b][h] xhat[b][k]      (A from LDS, B = xhat registers)
 //     dxhat[b][k] += sum_h dZ[b][h] W[h][k]        (A from LDS, B = the weight registers)
 // then Adam in registers and 16-byte stores.  Cache policy (template mask NTM: 1 = m,v loads, 8 = m,v
