@@ -49,6 +49,9 @@ __device__ __forceinline__ void ch_adam_fast(float& w, float& m, float& v, float
 // compiler waits for the 12 KB prefetch it has just issued before the first use of the CURRENT register set (its
 // per-register wait counts are merged conservatively around the loop), so nothing overlaps.  The "memory" clobbers keep
 // these loads, the compiler's own stores and the waits in program order, which is what the counts below rely on.
+// Every untracked load is issued UNCONDITIONALLY (a dummy address where there is nothing to fetch): the compiler believes
+// an asm output is valid at once, so a load under a branch would meet "not loaded" in a phi, and a copy inserted for that
+// phi would read the register before the data lands.  tests/test_chain_asm.py checks the generated code for exactly that.
 // 16 bytes at (wave-uniform base) + (32-bit byte offset of the lane) + OFF: one offset register serves W1, m and v
 template <int OFF, bool NT>
 __device__ __forceinline__ void ch_gload16(f32x4& v, const float* base, uint32_t voff) {
@@ -60,14 +63,9 @@ __device__ __forceinline__ void ch_gstore16(const f32x4& v, float* base, uint32_
     if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
-// 4 bytes at (wave-uniform base) + (32-bit byte offset of the lane)
-__device__ __forceinline__ void ch_gload4(uint32_t& v, const float* base, uint32_t voff) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base) : "memory");
-}
-__device__ __forceinline__ void ch_gload8(uint32_t& v0, uint32_t& v1, const void* p) {
-    uint2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    v0 = v.x; v1 = v.y;
+// 4 bytes at a per-lane 64-bit address
+__device__ __forceinline__ void ch_gload4(uint32_t& v, const void* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 }
 // Wait until at most N vector-memory operations are outstanding; the operands tie the registers the wait protects, so
 // no use of them can be scheduled above it.  COUNTING RULE (gfx9 has one counter for loads and stores): loads retire in
@@ -130,8 +128,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // byte offset of this lane's first 16 bytes of unit (kt, w) in each of W1S / m / v  (Kp * 1024 < 2^32: checked by the launcher)
     auto unit_off = [&](int kt) { return (uint32_t)(((uint32_t)kt * NHT + w) * 4096u + lane * 16u); };
     auto load_unit = [&](int kt, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
-        // 12 loads, always: the wait counts below depend on it
-        const uint32_t o = unit_off(kt);
+        // 12 loads, ALWAYS (the wait counts depend on it).  kt < 0: nothing left to fetch -- the same 12 instructions with
+        // ONE address for the whole wave (one 16-byte request each instead of 1 KB), a different line per wave so that
+        // the 2048 waves do not queue on one channel; results unused
+        const uint32_t o = kt >= 0 ? unit_off(kt) : (uint32_t)((((uint32_t)blockIdx.x * NHT + w) & 2047u) * 64u);
         ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0>(vq[0], v1s, o);
         ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0>(vq[1], v1s, o);
         ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0>(vq[2], v1s, o);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     };
     // The first unit is requested before anything else; the prologue ends with vmcnt(0).
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
-    if ((int)blockIdx.x < nkt) load_unit(blockIdx.x, wA, mA, vA);
+    load_unit((int)blockIdx.x < nkt ? (int)blockIdx.x : -1, wA, mA, vA);
 
     for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
     if (t < 32) {
@@ -170,20 +170,25 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // stage() puts them into sm[buf] an iteration later (under load a small load takes about as long as a big one).
     uint32_t ld0 = 0u, ld1 = 0u, ld2 = 0u;
     auto fetch = [&](int kt) {
-        const int k = kt * KT + jl;
-        if (w <= 3) {
-            const int pc = (w & 1) * 64 + lane;                       // 8-byte piece of the [32 rows][32 bytes] tile
-            const int row = w <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];
-            if (w <= 1 || chain) ch_gload8(ld0, ld1, X + (int64_t)row * pitch + (int64_t)kt * KT + 8 * (pc & 3));
-        } else if (w == 4) {
-            ch_gload4(ld0, bn4, 4u * (uint32_t)(hi * Kp + k));
-            ch_gload4(ld1, bn4, 4u * (uint32_t)((2 + hi) * Kp + k));
-        } else if (w == 5) {
-            const uint32_t o = 4u * (uint32_t)(gbo + k);
-            ch_gload4(ld0, gamma, o); ch_gload4(ld1, m_gamma, o); ch_gload4(ld2, v_gamma, o);
-        } else if (w == 6) {
-            if (chain) ch_gload4(ld0, next_stats, 4u * (uint32_t)(hi * Kp + k));
+        // three 4-byte loads per lane, ALWAYS; the role (and kt < 0: nothing left to fetch) only chooses the addresses
+        const int ktc = kt >= 0 ? kt : (int)blockIdx.x;
+        const int k = ktc * KT + jl;
+        const void *a0 = alpha_tab + w, *a1 = a0, *a2 = a0;            // wave 7, and every "nothing to fetch" case: one read-only word per wave
+        if (kt >= 0) {
+            if (w <= 3) {
+                const int pc = (w & 1) * 64 + lane;                   // 8-byte piece of the [32 rows][32 bytes] tile
+                const int row = w <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];      // (no next minibatch: row 0, unused)
+                const uint8_t* a = X + (int64_t)row * pitch + (int64_t)ktc * KT + 8 * (pc & 3);
+                a0 = a; a1 = a + 4; a2 = a;
+            } else if (w == 4) {
+                a0 = bn4 + (int64_t)hi * Kp + k; a1 = bn4 + (int64_t)(2 + hi) * Kp + k; a2 = a0;
+            } else if (w == 5) {
+                a0 = gamma + gbo + k; a1 = m_gamma + gbo + k; a2 = v_gamma + gbo + k;
+            } else if (w == 6 && chain) {
+                a0 = next_stats + (int64_t)hi * Kp + k; a1 = a0; a2 = a0;
+            }
         }
+        ch_gload4(ld0, a0); ch_gload4(ld1, a1); ch_gload4(ld2, a2);
     };
     auto stage = [&](int buf) {
         float* b = sm + buf * CH_SM;
@@ -210,12 +215,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     };
     {
         const int kt = blockIdx.x;
-        if (kt < nkt) {
-            fetch(kt);
-            ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
-            stage(0);
-        }
-        if (kt + G < nkt) fetch(kt + G);                      // staged at the end of the first iteration
+        fetch(kt < nkt ? kt : -1);
+        ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
+        if (kt < nkt) stage(0);
+        fetch(kt + G < nkt ? kt + G : -1);                      // staged during the first iteration
         ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
     }
     __syncthreads();
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     f32x16 facc = {0};
 
     // Vector-memory operations of one iteration, in program order (the hand-counted wait depends on it):
-    //   12 prefetch loads (kt_next >= 0) | wait | 12 stores of this unit | 0..3 small loads of tile + 2 | barrier | 0..5 small stores
+    //   12 prefetch loads | wait | 12 stores of this unit | 3 small loads of tile + 2 | barrier | 0..5 small stores
     auto step = [&](int kt, int kt_next, int kt_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
                     f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
         const int k = kt * KT + jl;
@@ -255,12 +258,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         float pv = smc[640 + lane], pm = smc[704 + lane], pvv = smc[768 + lane];
         float nmu = smc[832 + jl], nvar = smc[864 + jl];
         const u32x4 xr = *reinterpret_cast<const u32x4*>(smc + 256 + jl * 8 + 4 * hi);
-        // ONE wait per iteration, right after the next unit's 12 loads: "at most 12 outstanding" proves every older load
-        // landed -- this unit (requested an iteration ago) and the next tile's small operands ld0..2 (requested at the end of
-        // the previous iteration).  On the last tile nothing is issued and everything is awaited.  One tied wait for both
-        // cases: two would meet in a phi and cost a copy of the whole register set.
-        if (kt_next >= 0) load_unit(kt_next, wn, mn, vn);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ONE wait per iteration, right after the next unit's 12 loads (always 12: dummies on the last tile): "at most 12
+        // outstanding" proves every older load landed -- this unit (requested an iteration ago) and the next tile's small
+        // operands ld0..2 (requested at the end of the previous iteration).
+        load_unit(kt_next, wn, mn, vn);
         ch_wait_unit<12>(wq, mq, vq, ld0, ld1, ld2);
 
         // ONE fp32 MFMA chain per unit:  Gn[h][k] = sum_b dZ[b][h] xn[b][k]  (D[i = unit][j = SNP], contraction over the
@@ -314,10 +315,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         }
         // The next tile's small operands (landed: see the wait above) go to the other LDS buffer, then the request for
         // the tile after next.
-        if (kt_next >= 0 && !(LOC_CHAIN_ABLATE & 2)) {
-            stage(par ^ 1);
-            if (kt_next2 >= 0) fetch(kt_next2);
-        }
+        if (kt_next >= 0 && !(LOC_CHAIN_ABLATE & 2)) stage(par ^ 1);
+        fetch(kt_next2);
 #if !(LOC_CHAIN_ABLATE & 1)
         // every wave's (dgamma | dbeta) partial of this k-tile and the next tile's small operands are in LDS; all reads
         // of this tile's small operands are above this line, so the buffer is free for tile + 2 after it
@@ -369,6 +368,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             if (kt + G < nkt) step(kt + G, nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
         }
     }
+    // the last iteration's dummy requests are still in flight: nothing below may reuse their registers before they land
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (chain) {
         // D[i = row b][j = unit]: lane holds unit w*32 + jl, rows rowmap(r, hi) -- the layout l1_reduce_kernel sums
         float* pout = partial_out + (int64_t)blockIdx.x * 32 * Hp;
