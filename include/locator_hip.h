@@ -411,6 +411,17 @@ int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int
  * kernels), 1..3 = bf16 pieces (loc_l1_image_build), 12 / 13 = int8 with 2 / 3 digit planes (loc_l1_image_i8_build). */
 int loc_predict_image_mode(const loc_net* net, int n);
 
+/* ---- 2-bit packed genotypes for the many-row int8 GEMM (diploid calls 0 / 1 / 2: locator.py:196-218) ----
+ * loc_pack_genotypes_2bit: X2[r][j] = sum_i (X[r][4 j + i] & 3) << 2 i  for a matrix whose values are known to be <= 3
+ * (loc_genotype_max); X2 pitch >= Kp / 4, 4-byte aligned.  loc_l1_forward_gemm_i8_packed = loc_l1_forward_gemm_i8 reading
+ * that matrix: a quarter of the genotype bytes and HBM lines, expanded to int8 in LDS; results are bit-identical to the
+ * unpacked call (integer arithmetic).  loc_predict uses it when net->X2 is set. */
+int loc_pack_genotypes_2bit(const uint8_t* X, int64_t x_pitch, int n_rows, int Kp, uint8_t* X2, int64_t x2_pitch,
+                            void* stream);
+int loc_l1_forward_gemm_i8_packed(const uint8_t* X2, int64_t x2_pitch, const int32_t* rows, int n, const loc_dims* d,
+                                  const void* image, int digits, const float* b1, float* partial, int64_t partial_floats,
+                                  float* a1, int target_blocks, const loc_tuning* tune, void* stream);
+
 /* thin event helpers so a ctypes host can time a kernel on the stream it runs on */
 int loc_event_create(void** ev);
 int loc_event_create_notiming(void** ev);

@@ -121,6 +121,9 @@ SIGNATURES = {
     "loc_l1_chain_supported": (C.c_int, [C.c_int]),
     "loc_l1_backward_adam_chain": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, vp, vp] + [vp] * 12
                                    + [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(Tuning), vp]),
+    "loc_pack_genotypes_2bit": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int64, vp]),
+    "loc_l1_forward_gemm_i8_packed": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, vp, vp, C.c_int64,
+                                                vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_predict_image_mode": (C.c_int, [C.POINTER(Net), C.c_int]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),

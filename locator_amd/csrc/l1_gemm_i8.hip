@@ -211,6 +211,15 @@ constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1
 #define G8_DMA_MOD "" /* cache-policy modifier of the genotype DMA (" nt", " sc1": measured, within 2 %)            */
 #endif
 
+// PACKED genotypes (template flag PK): rows of 2-bit genotypes (values 0..3, four SNPs per byte: loc_pack_genotypes_2bit),
+// a quarter of the HBM lines and of the bytes per request.  The DMA moves 4 bytes per lane (8 rows x 32 bytes per request,
+// the same number of requests per wave and pair, so every hand count above holds) into a ring of G8_RPK pairs x 4 KB behind
+// the epilogue's staging area; it runs ONE pair further ahead, and after the rendezvous of pair pc every thread expands
+// two (UT = 2: four) packed words of pair pc + 2 into the int8 ring, which the rendezvous of pair pc + 1 publishes.
+#define G8_PKOFF G8_LDS   /* byte offset of the packed ring in the kernel's LDS                                       */
+#define G8_RPK 4          /* pairs in the packed ring >= G8_LA + 2                                                      */
+#define G8_LDS_PK (G8_LDS + G8_RPK * 4096)
+
 struct g8_ctx {
     const uint8_t* xrow[4];       // this lane's genotype rows (DMA role): rows 16 UT w + 8 i + (lane >> 3), i < 2 UT
     uint32_t xpiece[4];           // 16 x the piece of the pair's 128-byte line this lane fetches for each of them
@@ -228,6 +237,17 @@ __device__ __forceinline__ void dma16_i8(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+__device__ __forceinline__ void dma4_i8(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" G8_DMA_MOD "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// four 2-bit genotypes (one byte, least significant pair first) -> four int8 in one word
+__device__ __forceinline__ uint32_t g8_expand4(uint32_t b) {
+    uint32_t x = (b | (b << 12)) & 0x000F000Fu;            // genotypes 1,0 in bits 3:0, genotypes 3,2 in bits 19:16
+    return (x | (x << 6)) & 0x03030303u;                    // ... each in the low two bits of its own byte
+}
+
 // One walk over this workgroup's SNP blocks with D digit planes [plane0, plane0 + D) of the DT planes in the image, by a
 // wave that owns UT unit tiles (UT = 1: eight waves per workgroup, two per SIMD, 256 registers each; UT = 2: four waves,
 // one per SIMD with the whole 512-register file - twice the accumulators and room for NB = 32 fragments in flight).
@@ -241,20 +261,50 @@ __device__ __forceinline__ void dma16_i8(const void* gsrc, uint32_t lds_dst) {
 // rendezvous sits in the middle of the pair - before it the wave waits for its own share of the NEXT pair's DMA - so
 // the first step of the next pair is prefetched half a pair ahead of its use and nobody waits for an LDS round trip
 // after it; with two waves per SIMD they are NOT phase-locked: whichever has operands feeds the matrix pipe.
-template <int D, int DT, int UT, int NB>
+template <int D, int DT, int UT, int NB, bool PK>
 __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&acc)[D][UT][4]) {
     constexpr int FP = 4 * D * UT;                          // fragments per pair
     constexpr int DPW = 2 * UT;                             // genotype DMAs per wave and pair
     // pairs per unrolled body, so that the ring slot of every fragment is static: the smallest UP with UP FP % NB == 0
     constexpr int UP = (FP % NB == 0) ? 1 : ((2 * FP) % NB == 0) ? 2 : ((3 * FP) % NB == 0) ? 3 : 4;
-    static_assert((UP * FP) % NB == 0 && G8_RP >= G8_LA + 2, "ring / unroll shapes");
+    static_assert((UP * FP) % NB == 0 && G8_RP >= G8_LA + 2 && G8_RPK >= G8_LA + 2, "ring / unroll shapes");
     const uint32_t lds0 = lds_addr32_i8(c.As);
     auto dma_x = [&](int pc, int i) {
         int cc = pc < c.cntp ? pc : c.cntp - 1;
         if (LOC_GEMM_ABLATE & 16) cc = 0;
+        if (LOC_GEMM_ABLATE & 32) cc &= ~3;                 // four consecutive pairs fetch the same lines: 1/4 of them from HBM
+        if (PK) {
+            uint32_t koff = (uint32_t)(c.p0 + cc) * 32 + c.xpiece[i];           // 32 packed bytes per row and pair
+            if (koff > (uint32_t)(c.Kp / 4 - 4)) koff = c.Kp / 4 - 4;          // only in the zero-weight padding of the last pair
+            dma4_i8(c.xrow[i] + koff, lds0 + G8_PKOFF + (pc % G8_RPK) * 4096 + (16 * UT * c.w + 8 * i) * 32);
+            return;
+        }
         uint32_t koff = (uint32_t)(c.p0 + cc) * (2 * G8_BK) + c.xpiece[i];
         if (koff > (uint32_t)(c.Kp - 16)) koff = c.Kp - 16; // only in the zero-weight padding of the last pair
         dma16_i8(c.xrow[i] + koff, lds0 + (pc % G8_RP) * (2 * G8_AIMG) + (16 * UT * c.w + 8 * i) * 128);
+    };
+    // PK: packed pair pc (landed, published by a barrier) -> int8 ring slot of pair pc: packed word d = 8 m + j is row m,
+    // SNPs 16 j .. 16 j + 15 of the pair = the row's 16-byte piece j, which sits at the XOR-swizzled slot the DMA of the
+    // unpacked form would have given it
+    constexpr int NTH = G8_NT / UT, NPK = 1024 / NTH;        // threads, packed words per thread and pair
+    auto unpack_read = [&](int pc, uint32_t (&pk)[NPK]) {
+        const unsigned char* src = c.As + G8_PKOFF + (pc % G8_RPK) * 4096;
+#pragma unroll
+        for (int e = 0; e < NPK; ++e) pk[e] = *reinterpret_cast<const uint32_t*>(src + 4 * (c.w * 64 + c.lane + NTH * e));
+    };
+    auto unpack_write1 = [&](int pc, uint32_t pkv, int e) {
+        unsigned char* dst = c.As + (pc % G8_RP) * (2 * G8_AIMG);
+        const int d = c.w * 64 + c.lane + NTH * e, m = d >> 3, j = d & 7;
+        u32x4 o;
+        o[0] = g8_expand4(pkv & 255u); o[1] = g8_expand4((pkv >> 8) & 255u);
+        o[2] = g8_expand4((pkv >> 16) & 255u); o[3] = g8_expand4(pkv >> 24);
+        *reinterpret_cast<u32x4*>(dst + m * 128 + ((j ^ ((m >> 1) & 7)) << 4)) = o;
+    };
+    auto unpack = [&](int pc) {
+        uint32_t pk[NPK];
+        unpack_read(pc, pk);
+#pragma unroll
+        for (int e = 0; e < NPK; ++e) unpack_write1(pc, pk[e], e);
     };
     // Fragment j = (step * D + p) * UT + ut of a pair sits at  pair base + voff[j],
     //   voff[j] = lane part (unit tile UT w + ut) + e DT TILE + kk 8192 + p TILE      (step = 2 e + kk)
@@ -281,13 +331,18 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
     i32x4 B[NB];
     i32x4 A[2][4];
 #pragma unroll
-    for (int pc = 0; pc < G8_LA; ++pc)
+    for (int pc = 0; pc < G8_LA + (PK ? 1 : 0); ++pc)
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma_x(pc, i);
 #pragma unroll
     for (int f = 0; f < NB; ++f) load_b(B[f], pair_base(f / FP), voff[f % FP]);
     wait_vm_i8<0>();
     barrier_i8();
+    if (PK) {                                               // pairs 0 and 1 expanded before the loop, pair pc + 2 inside it
+        unpack(0);
+        unpack(1);
+        barrier_i8();
+    }
     rd4_i8(A[0][0], A[0][1], A[0][2], A[0][3], aoff[0]);
 
     constexpr int N_DMA = (G8_LA - 1) * (DPW + FP) + FP / 2;
@@ -296,7 +351,7 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
         const int pc = pc0 + u;
         if (!(LOC_GEMM_ABLATE & 2)) {
 #pragma unroll
-            for (int i = 0; i < DPW; ++i) dma_x(pc + G8_LA, i);
+            for (int i = 0; i < DPW; ++i) dma_x(pc + G8_LA + (PK ? 1 : 0), i);
         }
         const uint32_t so = (pc % G8_RP) * (2 * G8_AIMG), so1 = ((pc + 1) % G8_RP) * (2 * G8_AIMG);
         // the pairs the fragments requested in this iteration belong to: NB fragments ahead
@@ -305,8 +360,9 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if (st == 2 && !(LOC_GEMM_ABLATE & 4)) {
-                wait_vm_i8<N_DMA>();                        // my rows of pair pc + 1 are in the ring
+                wait_vm_i8<N_DMA>();                        // my rows of pair pc + 1 (PK: packed pair pc + 2) are in the ring
                 barrier_i8();                               // ... and so are everyone's; nobody still reads pair pc - 1
+                //                                            (PK: and pair pc + 1, expanded during the last half pair, is complete)
             } else {
                 wait_lgkm0_i8();                            // A[st & 1] has landed
             }
@@ -333,6 +389,17 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
                     for (int tm = 0; tm < 4; ++tm)
                         acc[p][ut][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[st & 1][tm], B[slot], acc[p][ut][tm], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    // PK: the expansion rides behind the first MFMA group after the rendezvous (vector ALU and LDS are idle
+                    // while the matrix pipe works through the four MFMAs just issued)
+                    if (PK && st >= 2) {                    // one packed word behind each MFMA group of steps 2 and 3
+                        constexpr int GPS = D * UT;         // MFMA groups per step
+                        const int gi = (st - 2) * GPS + p * UT + ut;
+                        if (gi < NPK) {                     // read + expand + store one word: no register is held across groups
+                            const unsigned char* src = c.As + G8_PKOFF + ((pc + 2) % G8_RPK) * 4096;
+                            unpack_write1(pc + 2, *reinterpret_cast<const uint32_t*>(src + 4 * (c.w * 64 + c.lane + NTH * gi)), gi);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     if (!(LOC_GEMM_ABLATE & 1)) load_b(B[slot], (j + NB % FP) < FP ? sb_lo : sb_hi, voff[(j + NB) % FP]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -361,7 +428,7 @@ __device__ __forceinline__ void g8_sweep(const g8_ctx& c, int plane0, i32x16 (&a
 
 // UT = 1: 512 threads, a wave = 128 rows x 32 units, 12 fragments in flight; UT = 2: 256 threads, one wave per SIMD,
 // a wave = 128 rows x 64 units, 32 fragments in flight.
-template <int DT, int UT>
+template <int DT, int UT, bool PK = false>
 __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* __restrict__ X, int64_t pitch,
                                                                  const int32_t* __restrict__ rows, int n, int Kp,
                                                                  const unsigned char* __restrict__ tiles,
@@ -402,8 +469,8 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
         const int m = 16 * UT * c.w + 8 * i + (lane >> 3);  // row of the 128-row tile this lane moves
         int r = mt * G8_BM + m;
         if (r > n - 1) r = n - 1;
-        c.xrow[i] = X + (int64_t)rows[r] * pitch;
-        c.xpiece[i] = (uint32_t)(((lane & 7) ^ ((m >> 1) & 7)) << 4);
+        c.xrow[i] = X + (int64_t)rows[r] * pitch;           // PK: X / pitch are the packed matrix's
+        c.xpiece[i] = PK ? (uint32_t)((lane & 7) << 2) : (uint32_t)(((lane & 7) ^ ((m >> 1) & 7)) << 4);
     }
     const int Mp = n_mt * G8_BM;
 
@@ -414,7 +481,7 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) acc[p][ut][tm] = i32x16{0};
-    g8_sweep<2, DT, UT, NB>(c, 0, acc);
+    g8_sweep<2, DT, UT, NB, PK>(c, 0, acc);
 
     // D[i = row][j = unit] x delta_j: wave tile 128 rows x WU units through a wave-private LDS image, then 16-byte stores.
     // Three planes: the two leading ones go out first (65536 * plane 0 + 256 * plane 1, in units of delta), the K range
@@ -455,7 +522,7 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) lo[0][ut][tm] = i32x16{0};
-        g8_sweep<1, DT, UT, NB>(c, 2, lo);
+        g8_sweep<1, DT, UT, NB, PK>(c, 2, lo);
         emit(lo[0], lo[0], 1.f, 0.f, true);
     }
 }
@@ -506,10 +573,9 @@ extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift
     return gm_launch_cvec(cpart, nkt, cvec, stream);
 }
 
-extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
-                                      const void* image, int digits, int x_max, const float* b1, float* partial,
-                                      int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune,
-                                      void* stream) {
+static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d, const void* image,
+                      int digits, int x_max, const float* b1, float* partial, int64_t partial_floats, float* a1,
+                      int target_blocks, const loc_tuning* tune, bool packed, void* stream) {
     if (n < 1) { loc_set_error("loc_l1_forward_gemm_i8: n=%d", n); return -1; }
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) {
         loc_set_error("loc_l1_forward_gemm_i8: width %d / %d digits unsupported", d->Hp, digits);
@@ -520,7 +586,13 @@ extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const i
                       x_max);
         return -1;
     }
-    if (d->Kp < 16 || d->Kp % 16 || x_pitch % 16 || x_pitch < d->Kp || ((uintptr_t)X & 15)) {
+    if (packed) {
+        if (x_max > 3 || d->Kp % 16 || x_pitch % 4 || x_pitch < d->Kp / 4 || ((uintptr_t)X & 3)) {
+            loc_set_error("loc_l1_forward_gemm_i8_packed: needs genotypes <= 3 (x_max = %d), a 4-byte aligned packed matrix and "
+                          "a 4-byte row pitch >= Kp / 4", x_max);
+            return -1;
+        }
+    } else if (d->Kp < 16 || d->Kp % 16 || x_pitch % 16 || x_pitch < d->Kp || ((uintptr_t)X & 15)) {
         loc_set_error("loc_l1_forward_gemm_i8: needs a 16-byte aligned X, Kp %% 16 == 0 and a 16-byte row pitch >= Kp");
         return -1;
     }
@@ -547,13 +619,19 @@ extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const i
     hipStream_t st = (hipStream_t)stream;
 #define G8_LAUNCH(DTV, UTV)                                                                                     \
     {                                                                                                           \
-        LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, UTV>), G8_LDS);                                                  \
-        hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, UTV>), dim3(n_mt * G), dim3(G8_NT / UTV), G8_LDS, st, X, x_pitch, \
-                           rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);                            \
+        if (packed) {                                                                                           \
+            LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, 1, true>), G8_LDS_PK);                                       \
+            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, 1, true>), dim3(n_mt * G), dim3(G8_NT), G8_LDS_PK, st, X,    \
+                               x_pitch, rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);               \
+        } else {                                                                                                \
+            LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, UTV, false>), G8_LDS);                                       \
+            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, UTV, false>), dim3(n_mt * G), dim3(G8_NT / UTV), G8_LDS, st, X, \
+                               x_pitch, rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);               \
+        }                                                                                                       \
     }
     const int ut = tune && (tune->gemm_i8_unit_tiles == 1 || tune->gemm_i8_unit_tiles == 2) ? tune->gemm_i8_unit_tiles
                                                                                              : G8_WAVE_UNIT_TILES;
-    if (ut == 2) {
+    if (ut == 2 && !packed) {             // (packed genotypes: the 8-wave form only; the 4-wave form has no registers left for the expansion)
         if (digits == 2) G8_LAUNCH(2, 2) else G8_LAUNCH(3, 2)
     } else {
         if (digits == 2) G8_LAUNCH(2, 1) else G8_LAUNCH(3, 1)
@@ -561,4 +639,20 @@ extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const i
 #undef G8_LAUNCH
     LOC_CHECK_LAUNCH();
     return gm_launch_reduce(partial, G, (int64_t)Mp * G8_HP, cvec, b1, a1, stream);
+}
+
+extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
+                                      const void* image, int digits, int x_max, const float* b1, float* partial,
+                                      int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune,
+                                      void* stream) {
+    return g8_forward(X, x_pitch, rows, n, d, image, digits, x_max, b1, partial, partial_floats, a1, target_blocks, tune,
+                      false, stream);
+}
+
+extern "C" int loc_l1_forward_gemm_i8_packed(const uint8_t* X2, int64_t x2_pitch, const int32_t* rows, int n,
+                                             const loc_dims* d, const void* image, int digits, const float* b1,
+                                             float* partial, int64_t partial_floats, float* a1, int target_blocks,
+                                             const loc_tuning* tune, void* stream) {
+    return g8_forward(X2, x2_pitch, rows, n, d, image, digits, 3, b1, partial, partial_floats, a1, target_blocks, tune, true,
+                      stream);
 }

@@ -135,6 +135,37 @@ extern "C" int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, i
     return 0;
 }
 
+// 2-bit packing of a genotype matrix whose values are 0..3 (loc_genotype_max): four SNPs per byte, SNP 4 j + i in bits
+// 2 i + 1 : 2 i of byte j.  One thread packs 16 SNPs into 4 bytes.
+__global__ __launch_bounds__(256) void pack_genotypes_2bit_kernel(const uint8_t* __restrict__ X, int64_t pitch, int Kp,
+                                                                  uint8_t* __restrict__ X2, int64_t pitch2) {
+    const int k16 = blockIdx.x * 256 + threadIdx.x;
+    if (k16 * 16 >= Kp) return;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (int64_t)blockIdx.y * pitch + 16 * k16);
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t a = v[q];
+        const uint32_t b = (a & 3u) | (((a >> 8) & 3u) << 2) | (((a >> 16) & 3u) << 4) | (((a >> 24) & 3u) << 6);
+        out |= b << (8 * q);
+    }
+    *reinterpret_cast<uint32_t*>(X2 + (int64_t)blockIdx.y * pitch2 + 4 * k16) = out;
+}
+
+extern "C" int loc_pack_genotypes_2bit(const uint8_t* X, int64_t x_pitch, int n_rows, int Kp, uint8_t* X2, int64_t x2_pitch,
+                                       void* stream) {
+    if (n_rows <= 0) return 0;
+    if (((uintptr_t)X & 15) || x_pitch % 16 || Kp % 16 || ((uintptr_t)X2 & 3) || x2_pitch % 4 || x2_pitch < Kp / 4) {
+        loc_set_error("loc_pack_genotypes_2bit: needs a 16-byte aligned X / row pitch, Kp %% 16 == 0 and a 4-byte aligned X2 with "
+                      "row pitch >= Kp / 4");
+        return -1;
+    }
+    hipLaunchKernelGGL(pack_genotypes_2bit_kernel, dim3((Kp / 16 + 255) / 256, n_rows), dim3(256), 0, (hipStream_t)stream, X,
+                       x_pitch, Kp, X2, x2_pitch);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int loc_w1_swizzle(const float* w_kh, int K, int H, float* w1s, int Kp, int Hp, void* stream) {
     int64_t n = (int64_t)Kp * Hp;
     hipLaunchKernelGGL(w1_swizzle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_kh,

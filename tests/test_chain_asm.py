@@ -129,7 +129,7 @@ def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_co
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("source,pattern,n_kernels", [("l1_gemm_i8.hip", r"^_Z17l1_gemm_i8_kernelILi", 4),
+@pytest.mark.parametrize("source,pattern,n_kernels", [("l1_gemm_i8.hip", r"^_Z17l1_gemm_i8_kernelILi", 6),
                                                       ("l1_gemm.hip", r"^_Z14l1_gemm_kernelILi", 3)])
 def test_large_m_gemm_kernels_keep_their_untracked_fragment_loads_untouched_until_counted(source, pattern, n_kernels):
     """The same property for the hand-counted weight-fragment loads of the many-row layer-1 GEMMs (l1_gemm_i8.hip,

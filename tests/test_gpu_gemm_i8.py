@@ -330,3 +330,69 @@ def test_hand_counted_vmcnt_build_equals_the_drained_build_bit_for_bit(repo_root
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert out[0] == out[1], out
+
+
+# ------------------------------------------------------------------ 2-bit packed genotypes
+def _pack(net):
+    from locator_amd import _lib
+    X2 = torch.zeros((net.X.shape[0], net.d.Kp // 4), dtype=torch.uint8, device="cuda")
+    _lib.check(net.lib.loc_pack_genotypes_2bit(net.X.data_ptr(), net.X.stride(0), net.X.shape[0], net.d.Kp, X2.data_ptr(),
+                                               X2.stride(0), None), "loc_pack_genotypes_2bit")
+    torch.cuda.synchronize()
+    return X2
+
+
+def test_pack_genotypes_2bit_matches_numpy():
+    x, y, p, rng = make_problem(37, 1003, 256, 2, seed=5)
+    x[rng.random(x.shape) < 0.05] = 3                       # 3 is a legal 2-bit value too
+    net = build_net(x, y, p)
+    X2 = _pack(net).cpu().numpy()
+    xp = np.zeros((37, net.d.Kp), np.uint8)
+    xp[:, :1003] = x
+    q = xp.reshape(37, -1, 4)
+    want = q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)
+    assert np.array_equal(X2, want)
+
+
+@pytest.mark.parametrize("digits", [2, 3])
+@pytest.mark.parametrize("K,n,target_blocks", [(8192, 1000, 0), (5830, 450, 0), (40000, 4096, 0), (3000, 300, 8),
+                                               (97, 130, 0), (20000, 700, 48)])
+def test_packed_genotypes_give_the_same_bits_as_the_unpacked_call(K, n, target_blocks, digits):
+    """loc_l1_forward_gemm_i8_packed on the 2-bit matrix against loc_l1_forward_gemm_i8 on the byte matrix: integer
+    products and sums of the same numbers, so every activation must agree bit for bit - for every loop shape (one pair
+    per group up to hundreds, K not a multiple of 128, rows not a multiple of 128, row indices that repeat)."""
+    from locator_amd import _lib
+    x, y, p, rng = make_problem(max(64, min(n, 1500)), K, 256, 2, seed=K % 71 + digits)
+    net = build_net(x, y, p)
+    d, lay, lib = net.d, net.lay, net.lib
+    rows = torch.from_numpy(rng.integers(0, x.shape[0], n).astype(np.int32)).cuda()
+    image, _ = build_image(net, digits)
+    ref = run_gemm_i8(net, rows, n, digits, target_blocks=target_blocks, image=image)
+    X2 = _pack(net)
+    mp = (n + 127) // 128 * 128
+    partial = torch.empty(256 * 128 * d.Hp, device="cuda")
+    a1 = torch.full((mp, d.Hp), float("nan"), device="cuda")
+    _lib.check(lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr(), X2.stride(0), rows.data_ptr(), n, C.byref(d),
+                                                 image.data_ptr(), digits, net.params.data_ptr() + 4 * lay.b1,
+                                                 partial.data_ptr(), partial.numel(), a1.data_ptr(), target_blocks, None,
+                                                 None), "loc_l1_forward_gemm_i8_packed")
+    torch.cuda.synchronize()
+    assert np.array_equal(ref[:n], a1.cpu().numpy()[:n])
+
+
+def test_packed_call_rejects_a_misaligned_matrix():
+    from locator_amd import _lib
+    x, y, p, rng = make_problem(64, 2000, 256, 2, seed=9)
+    net = build_net(x, y, p)
+    d, lay, lib = net.d, net.lay, net.lib
+    image, _ = build_image(net, 2)
+    X2 = _pack(net)
+    rows = torch.arange(640, dtype=torch.int32, device="cuda") % 64
+    partial = torch.empty(256 * 128 * d.Hp, device="cuda")
+    a1 = torch.zeros((640, d.Hp), device="cuda")
+    rc = lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr() + 1, X2.stride(0), rows.data_ptr(), 640, C.byref(d), image.data_ptr(), 2,
+                                           net.params.data_ptr() + 4 * lay.b1, partial.data_ptr(), partial.numel(),
+                                           a1.data_ptr(), 0, None, None)
+    assert rc != 0 and "packed" in lib.loc_last_error().decode()
+    rc = lib.loc_pack_genotypes_2bit(net.X.data_ptr(), net.X.stride(0), 64, d.Kp, X2.data_ptr(), d.Kp // 4 - 4, None)
+    assert rc != 0

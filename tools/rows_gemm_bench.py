@@ -35,6 +35,9 @@ def main():
                     help="size of the genotype matrix the rows are drawn from (rows = arange(n) %% matrix_rows): the batched "
                          "--jacknife re-reads a small matrix, so its lines come from L2 / MALL; 0 = every row distinct")
     ap.add_argument("--lib", default=None, help="another build of liblocator_hip.so (timing ablations)")
+    ap.add_argument("--packed", action="store_true",
+                    help="int8 GEMM on 2-bit packed genotypes (loc_pack_genotypes_2bit + loc_l1_forward_gemm_i8_packed); the "
+                         "result is checked bit for bit against the unpacked call")
     ap.add_argument("--unit-tiles", type=int, default=0,
                     help="int8 GEMM: loc_tuning.gemm_i8_unit_tiles (1 = eight waves per workgroup, 2 = four waves with 512 registers)")
     a = ap.parse_args()
@@ -100,11 +103,27 @@ def main():
                 _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, digits,
                                                      image.data_ptr(), None))
             for blocks in [int(b) for b in a.blocks.split(",")]:
-                def run():
+                def run_plain():
                     _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n, C.byref(d),
                                                           image.data_ptr(), digits, 2, P + 4 * lay.b1,
                                                           partial.data_ptr(), partial.numel(), a1.data_ptr(), blocks,
                                                           C.byref(_lib.Tuning(gemm_i8_unit_tiles=a.unit_tiles)), None))
+                run = run_plain
+                if a.packed:
+                    X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.loc_pack_genotypes_2bit(X.data_ptr(), X.stride(0), X.shape[0], d.Kp, X2.data_ptr(),
+                                                           X2.stride(0), None))
+
+                    def run():
+                        _lib.check(lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr(), X2.stride(0), rows.data_ptr(), n,
+                                                                     C.byref(d), image.data_ptr(), digits, P + 4 * lay.b1,
+                                                                     partial.data_ptr(), partial.numel(), a1.data_ptr(),
+                                                                     blocks, C.byref(_lib.Tuning(gemm_i8_unit_tiles=a.unit_tiles)),
+                                                                     None))
+                    prep(); run_plain(); torch.cuda.synchronize()
+                    ref = a1[:n].clone()
+                    run(); torch.cuda.synchronize()
+                    assert torch.equal(ref, a1[:n]), f"packed result differs: max {float((ref - a1[:n]).abs().max())}"
                 t = {}
                 for name, fn in (("prep", prep), ("gemm", run)):
                     for _ in range(5):
@@ -118,7 +137,7 @@ def main():
                     torch.cuda.synchronize()
                     t[name] = e0.elapsed_time(e1) * 1e3 / a.iters
                 flops = 2.0 * n * a.snps * a.width
-                rec = {"kernel": "int8 image+gemm", "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
+                rec = {"kernel": "int8 image+gemm" + (", 2-bit packed genotypes" if a.packed else ""), "blocks": blocks, "rows": n, "snps": a.snps, "width": a.width,
                        "digits": digits, "unit_tiles": a.unit_tiles, "us_gemm": round(t["gemm"], 2), "us_prep": round(t["prep"], 2),
                        "tflops": round(flops / t["gemm"] * 1e-6, 1),
                        "frac_bf16_peak": round(flops / t["gemm"] * 1e-6 / BF16_PEAK_TFLOPS, 4),
