@@ -172,7 +172,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
     at twice the bf16 rate: 3 digits cost 1.5 bf16-MFMA equivalents per product, 2 digits 1).  Shapes: M = every row of
     the matrix (model.predict over all samples); M = 4096 and M = 16384 (= LOC_PREDICT_CHUNK, what loc_predict launches at
     a time) rows drawn from it (the batched --jacknife: nboots x n_pred perturbed rows of the same matrix in one predict, so
-    genotype lines repeat and come from L2 / MALL); M = 4096
+    genotype lines repeat and come from L2 / MALL); M = 4096 and M = 16384
     DISTINCT rows of a second synthetic matrix (every genotype byte streams from HBM once).  Per shape and mode: us =
     GEMM + its reduction, mean of `iters` back-to-back launches replayed from a graph (the sustained, clocked-down
     rate); us_prep = the once-per-predict weight conversion (not in us; frac_bf16_peak_incl_prep has it); burst_of_3 =
@@ -268,7 +268,9 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
     res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)
     res["jacknife_shape_16384_rows"] = shape(net.X, 16384, n_matrix, in_loop=False)     # one LOC_PREDICT_CHUNK
     if x_distinct is not None:
-        res["distinct_4096_rows"] = shape(x_distinct, 4096, x_distinct.shape[0], in_loop=False)
+        res["distinct_4096_rows"] = shape(x_distinct[:4096], 4096, 4096, in_loop=False)
+        if x_distinct.shape[0] >= 16384:
+            res["distinct_16384_rows"] = shape(x_distinct, 16384, 16384, in_loop=False)
     return res
 
 
@@ -541,11 +543,14 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_l1_gemm:
-            # 4096 DISTINCT synthetic rows (0/1/2 genotypes drawn on the device) for the streaming shape of the GEMM
+            # 16,384 DISTINCT synthetic rows (0/1/2 genotypes drawn on the device, 4096 at a time) for the streaming shapes
+            # of the GEMM: the first 4096 of them, and all of them = one LOC_PREDICT_CHUNK launch of loc_predict
             g = torch.Generator(device=dev).manual_seed(4096)
-            u = torch.rand((4096, fits[0].net.d.Kp), device=dev, generator=g)
-            xd = ((u < 0.25).to(torch.uint8) + (u < 0.08).to(torch.uint8)).contiguous()
-            del u
+            xd = torch.empty((16384, fits[0].net.d.Kp), dtype=torch.uint8, device=dev)
+            for r0 in range(0, 16384, 4096):
+                u = torch.rand((4096, fits[0].net.d.Kp), device=dev, generator=g)
+                xd[r0:r0 + 4096] = (u < 0.25).to(torch.uint8) + (u < 0.08).to(torch.uint8)
+                del u
             out["l1_gemm"] = l1_gemm_roofline(fits[0].net, n, x_distinct=xd)
             del xd
         if not args.no_cpu_baseline and world == 1:
