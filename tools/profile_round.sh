@@ -33,6 +33,7 @@ cp $O/gemm_pmc_4096.json $O/${TAG}_gemm_pmc_4096.json
 rm -rf $O/gemm_kt
 rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000,4096 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
 cp $O/gemm_kt/k_kernel_stats.csv $O/${TAG}_gemm_kernel_stats.csv
+python3 $R/tools/rows_gemm_bench.py --rows 4096,16384 --iters 10 --i8-only --packed >> $O/${TAG}_gemm_bench.log 2>&1    # 2-bit packed genotypes
 tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
 tail -6 $O/pmc_traffic.log; tail -4 $O/gemm_pmc.log | cut -c1-400
