@@ -18,7 +18,7 @@ Deliberate, documented deviations:
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 4096 rows (the reference default is 32; above 32 it needs a --width that pads to 64,
     128 or 256 and --nlayers >= 4 with dropout; above 128 the step is correct but not tuned) and --width to 1024 (above 512: per-layer kernels);
-  * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
+  * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --no_chain / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
     the end of params.json).
 """
 from __future__ import annotations
@@ -86,6 +86,9 @@ def build_parser():
                    help="seconds one --windows / --bootstrap replicate may take inside a worker before that worker is "
                         "killed and replaced and the replicate reported as failed (default 0: no limit)")
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
+    p.add_argument("--no_chain", default=False, action="store_true",
+                   help="one layer-1 forward launch per minibatch step instead of chaining it into the previous step's "
+                        "layer-1 backward (the round-2 schedule; same results up to fp32 round-off, about 10 %% slower)")
     p.add_argument("--load_weights", default=None, type=str,
                    help="a .weights.npz written by --keep_weights: skip training and predict with these weights")
     p.add_argument("--predict_mode", default="exact", choices=("exact", "fast"),
@@ -350,7 +353,8 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
     else:
         history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
                       max_epochs=args.max_epochs, patience=earlystop["patience"], lr_patience=reducelr["patience"],
-                      lr_factor=reducelr["factor"], use_graph=not args.no_graph, verbose=args.keras_verbose)
+                      lr_factor=reducelr["factor"], use_graph=not args.no_graph, verbose=args.keras_verbose,
+                      chain=False if getattr(args, "no_chain", False) else None)
     if args.keep_weights:
         save_weights(checkpointer["filepath"], model.weights_dict())
     print("run time " + str((time.time() - start) / 60) + " minutes")

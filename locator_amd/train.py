@@ -162,12 +162,12 @@ class EpochRunner:
 
 
 def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
-        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print):
+        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print, chain=None):
     """train_network (locator.py:365-394): fit with checkpoint / early-stop / LR-plateau callbacks, then
     reload the best weights.  Returns a History.  lr_patience None = int(patience / 6) (locator.py:354)."""
     if len(val_rows) == 0:
         raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
-    runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph)
+    runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain)
     cb = Callbacks(patience, 1e-3, lr_patience, lr_factor)
     hist = History()
     rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))

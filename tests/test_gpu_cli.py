@@ -52,6 +52,23 @@ def test_single_run_writes_the_four_files_and_learns(tmp_path, capsys):
     assert pl["x"].std() > 5 and pl["y"].std() > 5
 
 
+def test_no_chain_flag_runs_the_unchained_schedule_to_the_same_fit(tmp_path, capsys):
+    """--no_chain (one layer-1 forward launch per step) against the chained default on the reference's example data: the
+    same permutations and masks, fp32 round-off apart - ten epochs of predictions within 1e-3 of the coordinate span."""
+    outs = []
+    for flags in ([], ["--no_chain"]):
+        out = str(tmp_path / ("c" + str(len(outs))))
+        _run(["--vcf", VCF, "--sample_data", SAMPLES, "--out", out, "--seed", "12345", "--max_epochs", "10",
+              "--patience", "10", "--keras_verbose", "0", "--plot_history", ""] + flags)
+        outs.append(out)
+    a, b = (pd.read_csv(o + "_predlocs.txt") for o in outs)
+    assert list(a["sampleID"]) == list(b["sampleID"])
+    assert np.abs(a[["x", "y"]].to_numpy() - b[["x", "y"]].to_numpy()).max() < 0.05          # coordinates span 0..50
+    ha, hb = (pd.read_csv(o + "_history.txt", sep="\t") for o in outs)
+    assert len(ha) == len(hb) == 10 and np.abs(ha["loss"] - hb["loss"]).max() < 1e-3
+    assert json.load(open(outs[1] + "_params.json"))["no_chain"] is True
+
+
 def test_bootstrap_outputs_and_run_to_run_determinism(tmp_path):
     outs = []
     for rep in range(2):
