@@ -6,6 +6,7 @@
 #   gpurun_out/<tag>_bench_replicates2.json      python3 bench.py --replicates-per-gpu 2
 #   gpurun_out/<tag>_bench_2ranks_selflaunch.json  python3 bench.py --gpus 2 --device-index 0 --dist-backend gloo (no launcher)
 #   gpurun_out/<tag>_pmc_traffic.json            FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh)
+#   gpurun_out/<tag>_chain_pmc.json              SQ counters of the chained layer-1 kernel (tools/chain_pmc.sh)
 #   gpurun_out/<tag>_gemm_pmc_1000.json, _4096.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters (with the effective
 #                                                 clock from GRBM_GUI_ACTIVE) and kernel times, int8 and bf16 kernels
 # Copy what should be judged into profiles/ (tracked).
@@ -26,6 +27,8 @@ cd /tmp
 rm -rf $O/prof_kt
 rocprofv3 --kernel-trace --stats -d $O/prof_kt -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2> $O/prof_kt.err
 cp $O/prof_kt/k_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
+bash $R/tools/chain_pmc.sh > $O/chain_pmc.log 2>&1               # counters of the chained layer-1 kernel alone
+cp $O/chain_pmc.json $O/${TAG}_chain_pmc.json
 bash $R/tools/gemm_pmc.sh 1000 > $O/gemm_pmc.log 2>&1
 bash $R/tools/gemm_pmc.sh 4096 >> $O/gemm_pmc.log 2>&1
 cp $O/gemm_pmc_1000.json $O/${TAG}_gemm_pmc_1000.json
