@@ -86,6 +86,25 @@ def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps():
     _assert_same_fit(p0, p1, m0, m1, v0, v1)
 
 
+def test_chained_epochs_equal_unchained_epochs_at_config4_width_of_snps():
+    """BASELINE.json configs[4]'s SNP count (500,000 after filtering: 15,625 k-tiles, 61 or 62 per workgroup; byte offsets
+    into W1 / m / v up to 2^29 in the kernel's 32-bit offset registers), 64 training rows = 2 minibatches, 1 epoch."""
+    K, width, nlayers, n_train = 500000, 256, 10, 64
+    rng = np.random.default_rng(4)
+    af = rng.beta(0.4, 0.9, K).clip(0.02, 0.98).astype(np.float32)
+    x = (rng.random((n_train + 10, K), dtype=np.float32) < af).astype(np.uint8) + \
+        (rng.random((n_train + 10, K), dtype=np.float32) < af).astype(np.uint8)
+    y = rng.normal(0, 1, (n_train + 10, 2))
+    p = O.init_params(K, width, nlayers, rng)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + 10)
+    perms = [np.random.default_rng(9).permutation(n_train)]
+    _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, 0.25, False)
+    _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, 0.25, False)
+    assert maxerr(h0, h1) < 2e-5, (h0, h1)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
+    assert np.abs(p1["W"][0] - p["W"][0]).max() > 1e-4 and np.abs(p1["W"][0][-40:] - p["W"][0][-40:]).max() > 1e-4   # trained, to the last SNP
+
+
 def test_chained_epochs_match_the_oracle_fit():
     """Chained schedule against oracle.fit with the same permutations and the device's dropout masks: 4 epochs x 4
     steps (last minibatch of 4 rows) at width 256.  Tolerances of test_short_fit_trajectory_matches_oracle_fit."""
