@@ -89,3 +89,29 @@ def test_codecs_library_loads_and_exports_its_entry_points(repo_root):
     lib = C.CDLL(os.path.join(repo_root, "locator_amd", "libloc_codecs.so"))
     for name in ("loc_lz4_decompress", "loc_blosc1_decompress", "loc_blosc1_info"):
         assert hasattr(lib, name), name
+
+
+def test_train_chain_supported_is_decided_by_shape_alone():
+    """loc_train_chain_supported is host logic over the loc_net fields (no kernel, no device memory): width padding to
+    256, at least one hidden layer, batch <= 32, Dropout not on the BatchNorm output, 16-byte row pitch, and the chained
+    kernel's 32-bit byte offsets (Kp * 1024 < 2^32: just under 4.2 million SNPs)."""
+    lib = _lib.load()
+
+    def net(K=100000, width=256, nlayers=10, drop=0.25, slot_rows=32, pitch=None, wht=1, grid=512):
+        n = _lib.Net()
+        n.d = _lib.make_dims(K, width, nlayers)
+        n.drop_p = drop
+        n.wht = wht                                # only tested for NULL here
+        n.slot_rows, n.l1_bwd_grid = slot_rows, grid
+        n.x_pitch = n.d.Kp if pitch is None else pitch
+        return n
+
+    ok = lambda **kw: bool(lib.loc_train_chain_supported(C.byref(net(**kw))))
+    assert ok() and ok(width=225) and ok(nlayers=2) and ok(drop=0.0) and ok(K=31)
+    assert not ok(width=224) and not ok(width=257) and not ok(width=64)
+    assert not ok(nlayers=1) and ok(nlayers=1, drop=0.0) is False
+    assert not ok(slot_rows=128)                                     # --batch_size > 32
+    assert not ok(wht=None)                                          # no fused hidden stack
+    assert not ok(pitch=100008)                                      # rows not 16-byte aligned
+    assert ok(K=4194240) and not ok(K=4194304)                       # Kp * 1024 < 2^32
+    assert ok(nlayers=3) and ok(nlayers=2, drop=0.25)                # Dropout after layer 1 is fine (n_pre = 1), only n_pre = 0 is not
