@@ -224,8 +224,8 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                 key = "int8x%d" % digits
                 out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
                 out[key]["tolerance"] = PREDICT_MODE_INFO[key]
-                # the same GEMM reading a 2-bit packed copy of the matrix (library capability, not what loc_predict does by
-                # itself: packing costs one pass over the matrix, see us_pack): bit-identical activations
+                # the same GEMM reading a 2-bit packed copy of the matrix (--predict_packed / loc_net.X2; not the default:
+                # packing costs one pass over the matrix, see us_pack): bit-identical activations
                 X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
                 pack = lambda: _lib.check(lib.loc_pack_genotypes_2bit(X.data_ptr(), X.stride(0), X.shape[0], d.Kp,
                                                                       X2.data_ptr(), X2.stride(0), st()))
@@ -237,7 +237,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                 keyp = key + "_packed2bit"
                 out[keyp] = timed(prep, runp, 0.5 * digits, n_rows * d.K / 4 + 1.0 * digits * d.K * d.H)
                 out[keyp]["us_pack"] = round(_time_graphed(pack, 5), 1)
-                out[keyp]["tolerance"] = PREDICT_MODE_INFO[key] + "; genotypes 0..3 stored 2 bits each (loc_pack_genotypes_2bit)"
+                out[keyp]["tolerance"] = PREDICT_MODE_INFO[key] + "; --predict_packed: genotypes 0..3 stored 2 bits each (loc_pack_genotypes_2bit)"
                 del image, X2
         for pieces in (3, 2, 1):
             key = "bf16x%d" % pieces

@@ -146,11 +146,18 @@ typedef struct loc_net {
                                 needs), otherwise a value loc_predict_image_mode() returned for an earlier loc_predict call
                                 since which neither the parameters nor the BatchNorm statistics changed - the conversion is
                                 then skipped (predict_locs predicts twice with the same weights, locator.py:414, :441) */
+    const uint8_t* X2;       /* optional: X packed 2 bits per genotype (loc_pack_genotypes_2bit; needs x_max <= 3), same rows.
+                                When set, row chunks of at least LOC_GEMM_I8_PACKED_MIN_ROWS rows of an int8 many-row predict
+                                read it instead of X (a quarter of the genotype traffic, bit-identical activations)        */
+    int64_t x2_pitch;
     loc_tuning tune;
 } loc_net;
 /* Rows from which the int8 image + GEMM beats the in-loop-conversion bf16x3 kernel including its once-per-call max pass
  * and conversion (K = 100,000, profiles/r03_gemm_bench.json). */
 #define LOC_GEMM_I8_MIN_ROWS(digits) 512
+/* rows per launch from which the int8 GEMM is faster on 2-bit packed genotypes (measured: 1000 rows 4 % slower, 4096 rows
+ * 12 % faster when the rows stream from HBM) */
+#define LOC_GEMM_I8_PACKED_MIN_ROWS 3072
 /* Rows from which image + GEMM beats the in-loop-conversion kernel INCLUDING the once-per-call conversion, measured at
  * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 51 / 30 us plus
  * 60 + 0.095 / 20 + 0.036 us per row). */

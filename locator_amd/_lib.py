@@ -48,7 +48,7 @@ class Net(C.Structure):
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
                 ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
                 ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("x_max", C.c_int), ("predict_digits", C.c_int),
-                ("l1_image_ready", C.c_int), ("tune", Tuning)]
+                ("l1_image_ready", C.c_int), ("X2", vp), ("x2_pitch", C.c_int64), ("tune", Tuning)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one

@@ -349,7 +349,10 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         }
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
-            if (i8)
+            if (i8 && net->X2 && net->x_max <= 3 && nc >= LOC_GEMM_I8_PACKED_MIN_ROWS)
+                TRY(loc_l1_forward_gemm_i8_packed(net->X2, net->x2_pitch, rows + c0, nc, d, net->l1_image, digits,
+                                                  P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, &net->tune, stream));
+            else if (i8)
                 TRY(loc_l1_forward_gemm_i8(net->X, net->x_pitch, rows + c0, nc, d, net->l1_image, digits, net->x_max,
                                            P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, &net->tune, stream));
             else if (gemm)

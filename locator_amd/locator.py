@@ -18,7 +18,7 @@ Deliberate, documented deviations:
     h5py is not available; the best-epoch snapshot itself lives in HBM, not on disk;
   * --batch_size is limited to 4096 rows (the reference default is 32; above 32 it needs a --width that pads to 64,
     128 or 256 and --nlayers >= 4 with dropout; above 128 the step is correct but not tuned) and --width to 1024 (above 512: per-layer kernels);
-  * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --no_chain / --net_seed / --load_weights / --predict_mode / --predict_pieces (recorded at
+  * extra flags --gpus / --fits_per_gpu / --unit_timeout / --no_graph / --no_chain / --net_seed / --load_weights / --predict_mode / --predict_packed / --predict_pieces (recorded at
     the end of params.json).
 """
 from __future__ import annotations
@@ -95,6 +95,10 @@ def build_parser():
                    help="first-layer arithmetic of many-row predictions on the int8 matrix pipe: exact = 24-bit fixed "
                         "point per weight (as accurate as fp32 accumulation; default), fast = 16-bit (predictions "
                         "within 1e-3 relative, tests/test_gpu_baseline_sizes.py)")
+    p.add_argument("--predict_packed", default=False, action="store_true",
+                   help="keep a 2-bit packed copy of every genotype matrix that is predicted from (values 0..3 only): "
+                        "predictions over 3072 rows or more then read a quarter of the genotype bytes, with identical "
+                        "results; pays when the same matrix is predicted from repeatedly (packing is one extra pass)")
     p.add_argument("--predict_pieces", default=None, type=int,
                    help="force the bf16 matrix pipe with this many pieces per first-layer weight instead: 3 = "
                         "fp32-exact products, 1 or 2 = faster, approximate (default: bf16 x 3 only where the int8 "
@@ -247,6 +251,8 @@ class Model:
             net.X, start = gen.X, gen.start
         else:
             net.X, start = upload_genotypes(np.asarray(gen), self.device), 0
+        if getattr(args, "predict_packed", False) and n >= 3072:
+            net.pack_genotypes()                      # cached on the matrix: a later predict from the same rows finds it
         net.cnet()
         rows = torch.arange(start, start + n, dtype=torch.int32, device=self.device)
         yhat = torch.zeros((n, 2), dtype=torch.float32, device=self.device)

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import locator_oracle as O
 from tests.gpu_util import build_net, make_problem, maxerr
 
 pytestmark = pytest.mark.gpu
@@ -396,3 +397,29 @@ def test_packed_call_rejects_a_misaligned_matrix():
     assert rc != 0 and "packed" in lib.loc_last_error().decode()
     rc = lib.loc_pack_genotypes_2bit(net.X.data_ptr(), net.X.stride(0), 64, d.Kp, X2.data_ptr(), d.Kp // 4 - 4, None)
     assert rc != 0
+
+
+def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bits():
+    """LocatorNet.pack_genotypes() + loc_predict: 4096 rows go through loc_l1_forward_gemm_i8_packed (loc_net.X2 set, chunk
+    >= LOC_GEMM_I8_PACKED_MIN_ROWS), 1000 rows through the unpacked call; predictions are bit-identical either way, and a
+    matrix with a genotype above 3 is left unpacked."""
+    x, y, p, rng = make_problem(700, 6000, 256, 4, seed=12)
+    net = build_net(x, y, p)
+    rows = torch.from_numpy(rng.integers(0, 700, 4096).astype(np.int32)).cuda()
+    out = {}
+    for packed in (False, True):
+        if packed:
+            assert net.pack_genotypes() and net.X.loc_x2.shape == (700, net.d.Kp // 4)
+        for n in (4096, 1000):
+            yhat = torch.zeros((n, 2), device="cuda")
+            net.predict_rows(rows, n, yhat)
+            torch.cuda.synchronize()
+            out[(packed, n)] = yhat.cpu().numpy().copy()
+        assert bool(net._net.X2) == packed
+    assert np.array_equal(out[(False, 4096)], out[(True, 4096)]) and np.array_equal(out[(False, 1000)], out[(True, 1000)])
+    ref = O.predict(p, x[rows.cpu().numpy()])
+    assert maxerr(out[(True, 4096)], ref) < 5e-5
+    x2 = x.copy()
+    x2[3, 17] = 4
+    net2 = build_net(x2, y, p)
+    assert net2.pack_genotypes() is False and getattr(net2.X, "loc_x2", None) is None
