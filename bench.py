@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="--batch_size of the fit (headline: 32, the reference default)")
     ap.add_argument("--replicates-per-gpu", type=int, default=1, help="independent fits per process on separate streams")
     ap.add_argument("--nt-mask", type=int, default=0, help="loc_tuning.l1b_nt_mask (cache-policy measurement switch)")
+    ap.add_argument("--stack-helpers", type=int, default=0, help="loc_tuning.stack_helpers (L2 warm-up workgroups of the hidden stack; measurement switch)")
     ap.add_argument("--separate-tail", action="store_true",
                     help="measurement switch (loc_tuning.chain_tail = -1): the hidden-layer Adam tail of a chained step as "
                          "its own launch instead of trailing workgroups of the chained layer-1 launch")
@@ -423,7 +424,8 @@ def main():
                 X = gather_columns(X0, so, K)
             self.net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=replicate, device=dev,
                                   tuning=({"l1b_nt_mask": args.nt_mask} if args.nt_mask else {}) |
-                                         ({"chain_tail": -1} if args.separate_tail else {}))
+                                         ({"chain_tail": -1} if args.separate_tail else {}) |
+                                         ({"stack_helpers": args.stack_helpers} if args.stack_helpers else {}))
             if args.l1_bwd_grid:
                 self.net.l1_bwd_grid = int(args.l1_bwd_grid)
             self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph,
