@@ -138,6 +138,7 @@ int loc_l1_reduce_launch_drop(const float* partial, int G, int rows_p, int Hp, c
             set__[dev__] = (size_t)(BYTES);                                                                  \
         }                                                                                                    \
     } while (0)
+#define LOC_GRID_Y_MAX 32768 /* HIP limits grid.y to 65535: kernels launched with one y-block per row stride over it */
 #define LOC_CHECK_LAUNCH()                                              \
     do {                                                                \
         hipError_t e__ = hipGetLastError();                             \

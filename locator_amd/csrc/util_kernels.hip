@@ -40,11 +40,12 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t n, uint3
 
 __global__ void gather_columns_kernel(const uint8_t* __restrict__ src, int64_t src_pitch,
                                       const int32_t* __restrict__ site_order, int K, uint8_t* __restrict__ dst,
-                                      int64_t dst_pitch) {
+                                      int64_t dst_pitch, int n_rows) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = blockIdx.y;
     if (j >= K) return;
-    dst[(int64_t)r * dst_pitch + j] = src[(int64_t)r * src_pitch + site_order[j]];
+    const int so = site_order[j];
+    for (int r = blockIdx.y; r < n_rows; r += gridDim.y)
+        dst[(int64_t)r * dst_pitch + j] = src[(int64_t)r * src_pitch + so];
 }
 
 __global__ void w1_swizzle_kernel(const float* __restrict__ w_kh, int K, int H, float* __restrict__ w1s, int Kp,
@@ -99,28 +100,30 @@ extern "C" int loc_dropout_mask_fill(uint8_t* mask, int64_t n, float p, uint64_t
 extern "C" int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const int32_t* site_order, int K,
                                   uint8_t* dst, int64_t dst_pitch, int n_rows, void* stream) {
     if (n_rows <= 0 || K <= 0) return 0;
-    hipLaunchKernelGGL(gather_columns_kernel, dim3((K + 255) / 256, n_rows), dim3(256), 0, (hipStream_t)stream, src,
-                       src_pitch, site_order, K, dst, dst_pitch);
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((K + 255) / 256, n_rows < LOC_GRID_Y_MAX ? n_rows : LOC_GRID_Y_MAX), dim3(256),
+                       0, (hipStream_t)stream, src, src_pitch, site_order, K, dst, dst_pitch, n_rows);
     LOC_CHECK_LAUNCH();
     return 0;
 }
 
 // largest genotype byte: 16 bytes per thread and step, wave maximum by shuffles, one atomicMax per wave
 __global__ __launch_bounds__(256) void genotype_max_kernel(const uint8_t* __restrict__ X, int64_t pitch, int K,
-                                                           uint32_t* __restrict__ out) {
-    const uint8_t* row = X + (int64_t)blockIdx.y * pitch;
+                                                           int n_rows, uint32_t* __restrict__ out) {
     uint32_t m = 0;
     const int K16 = K & ~15;
-    for (int k = (blockIdx.x * 256 + threadIdx.x) * 16; k < K16; k += gridDim.x * 256 * 16) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
+    for (int r = blockIdx.y; r < n_rows; r += gridDim.y) {        // grid.y is capped (LOC_GRID_Y_MAX): rows stride over it
+        const uint8_t* row = X + (int64_t)r * pitch;
+        for (int k = (blockIdx.x * 256 + threadIdx.x) * 16; k < K16; k += gridDim.x * 256 * 16) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t a = v[d];
-            m = max(m, max(max(a & 255u, (a >> 8) & 255u), max((a >> 16) & 255u, a >> 24)));
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t a = v[d];
+                m = max(m, max(max(a & 255u, (a >> 8) & 255u), max((a >> 16) & 255u, a >> 24)));
+            }
         }
+        if (blockIdx.x == 0)
+            for (int k = K16 + threadIdx.x; k < K; k += 256) m = max(m, (uint32_t)row[k]);
     }
-    if (blockIdx.x == 0)
-        for (int k = K16 + threadIdx.x; k < K; k += 256) m = max(m, (uint32_t)row[k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -130,7 +133,8 @@ extern "C" int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, i
     if (n_rows <= 0 || K <= 0) return 0;
     if (((uintptr_t)X & 15) || x_pitch % 16) { loc_set_error("loc_genotype_max: needs a 16-byte aligned X and row pitch"); return -1; }
     const int gx = K >= 65536 ? 8 : 1;
-    hipLaunchKernelGGL(genotype_max_kernel, dim3(gx, n_rows), dim3(256), 0, (hipStream_t)stream, X, x_pitch, K, out);
+    hipLaunchKernelGGL(genotype_max_kernel, dim3(gx, n_rows < LOC_GRID_Y_MAX ? n_rows : LOC_GRID_Y_MAX), dim3(256), 0,
+                       (hipStream_t)stream, X, x_pitch, K, n_rows, out);
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -138,18 +142,20 @@ extern "C" int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, i
 // 2-bit packing of a genotype matrix whose values are 0..3 (loc_genotype_max): four SNPs per byte, SNP 4 j + i in bits
 // 2 i + 1 : 2 i of byte j.  One thread packs 16 SNPs into 4 bytes.
 __global__ __launch_bounds__(256) void pack_genotypes_2bit_kernel(const uint8_t* __restrict__ X, int64_t pitch, int Kp,
-                                                                  uint8_t* __restrict__ X2, int64_t pitch2) {
+                                                                  uint8_t* __restrict__ X2, int64_t pitch2, int n_rows) {
     const int k16 = blockIdx.x * 256 + threadIdx.x;
     if (k16 * 16 >= Kp) return;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(X + (int64_t)blockIdx.y * pitch + 16 * k16);
-    uint32_t out = 0;
+    for (int r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(X + (int64_t)r * pitch + 16 * k16);
+        uint32_t out = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t a = v[q];
-        const uint32_t b = (a & 3u) | (((a >> 8) & 3u) << 2) | (((a >> 16) & 3u) << 4) | (((a >> 24) & 3u) << 6);
-        out |= b << (8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t a = v[q];
+            const uint32_t b = (a & 3u) | (((a >> 8) & 3u) << 2) | (((a >> 16) & 3u) << 4) | (((a >> 24) & 3u) << 6);
+            out |= b << (8 * q);
+        }
+        *reinterpret_cast<uint32_t*>(X2 + (int64_t)r * pitch2 + 4 * k16) = out;
     }
-    *reinterpret_cast<uint32_t*>(X2 + (int64_t)blockIdx.y * pitch2 + 4 * k16) = out;
 }
 
 extern "C" int loc_pack_genotypes_2bit(const uint8_t* X, int64_t x_pitch, int n_rows, int Kp, uint8_t* X2, int64_t x2_pitch,
@@ -160,8 +166,8 @@ extern "C" int loc_pack_genotypes_2bit(const uint8_t* X, int64_t x_pitch, int n_
                       "row pitch >= Kp / 4");
         return -1;
     }
-    hipLaunchKernelGGL(pack_genotypes_2bit_kernel, dim3((Kp / 16 + 255) / 256, n_rows), dim3(256), 0, (hipStream_t)stream, X,
-                       x_pitch, Kp, X2, x2_pitch);
+    hipLaunchKernelGGL(pack_genotypes_2bit_kernel, dim3((Kp / 16 + 255) / 256, n_rows < LOC_GRID_Y_MAX ? n_rows : LOC_GRID_Y_MAX),
+                       dim3(256), 0, (hipStream_t)stream, X, x_pitch, Kp, X2, x2_pitch, n_rows);
     LOC_CHECK_LAUNCH();
     return 0;
 }

@@ -614,6 +614,23 @@ def _print_replicate_summary(pool, results, t_program):
         print(line)
 
 
+def _unit_count_bound():
+    """Cheap upper bound on the number of replicate units, known before the prologue: the pool never spawns more worker
+    processes (each one imports torch, opens a device context and loads the HIP library) than there are units."""
+    if args.bootstrap:
+        return int(args.nboots) + 1                                   # FULL fit + replicates (locator.py:612-676)
+    if args.windows and args.zarr:
+        try:
+            if args.window_stop is not None:
+                last = int(args.window_stop)
+            else:
+                last = int(np.asarray(G.open_group(args.zarr, mode="r")["variants/POS"][:]).max())
+            return max(1, -(-(last - int(args.window_start)) // int(args.window_size)))
+        except Exception:                                             # noqa: BLE001 - the prologue reports the real problem
+            return None
+    return None
+
+
 def main(argv=None):
     t_program = time.time()
     _setup(argv)
@@ -626,7 +643,8 @@ def main(argv=None):
         lazy_windows = args.windows and not args.impute_missing and args.max_SNPs is None
         pool = replicates.ReplicatePool(args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu,
                                         host_prepare=_load_window_on_loader_thread if lazy_windows else None,
-                                        unit_timeout=getattr(args, "unit_timeout", 0)).start()
+                                        unit_timeout=getattr(args, "unit_timeout", 0),
+                                        max_workers=_unit_count_bound()).start()
     try:
         return _main_body(pool, t_program)
     finally:

@@ -102,31 +102,44 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent):
     box = {"shared": {}, "keep": []}
 
     def loader():
-        while True:
-            try:
-                item = conn.recv()
-            except (EOFError, OSError):
-                item = None
-            if item is None:
-                todo.put(None)
-                return
-            if item[0] == "shared":
-                box["shared"], box["keep"] = _attach(item[1], item[2])
-                continue
-            _, idx, unit = item
-            t1, err = time.time(), None
-            try:
-                if host_prepare is not None:
-                    unit = host_prepare(unit, args)
-            except Exception as e:                           # noqa: BLE001
-                err = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
-                       "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
-            todo.put((idx, unit, err, time.time() - t1))
+        # Anything that goes wrong OUTSIDE a unit's own host work (a shared-memory segment that cannot be attached, a
+        # message that does not unpickle) must not leave the main thread blocked on `todo` in a live process: the parent
+        # would see neither end-of-file nor a dead process.  It is handed over as a fatal item; the main thread reports
+        # ("dead", why) - only the main thread sends - and the process exits, so the parent buries it like any other loss.
+        try:
+            while True:
+                try:
+                    item = conn.recv()
+                except (EOFError, OSError):
+                    item = None
+                if item is None:
+                    todo.put(None)
+                    return
+                if item[0] == "shared":
+                    box["shared"], box["keep"] = _attach(item[1], item[2])
+                    continue
+                _, idx, unit = item
+                t1, err = time.time(), None
+                try:
+                    if host_prepare is not None:
+                        unit = host_prepare(unit, args)
+                except Exception as e:                       # noqa: BLE001
+                    err = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
+                           "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
+                todo.put((idx, unit, err, time.time() - t1))
+        except BaseException as e:                           # noqa: BLE001
+            todo.put(("fatal", f"worker loader thread failed: {type(e).__name__}: {e}"))
 
     threading.Thread(target=loader, daemon=True).start()
     while True:
         item = todo.get()
         if item is None:
+            break
+        if item[0] == "fatal":
+            try:
+                conn.send(("dead", item[1]))
+            except (OSError, ValueError):
+                pass
             break
         idx, unit, err, t_host = item
         conn.send(("start", idx))
@@ -336,6 +349,14 @@ class ReplicatePool:
                 self.failed_starts += 1
             if state["got"] < len(units) and (retry or state["next"] < len(units)) and self.failed_starts < 4 * self.n:
                 self._start_worker(w["gpu"])
+            feed_idle()                                  # requeued units go to workers that are ready NOW, not only to
+                                                         # whichever worker speaks next (or to a replacement's start-up)
+
+        def feed_idle():
+            for c in list(workers):
+                w2 = workers.get(c)
+                if w2 is not None and w2["ready"] and len(w2["inflight"]) < self.depth:
+                    feed(c)
 
         try:
             while state["got"] < len(units):
@@ -369,10 +390,18 @@ class ReplicatePool:
                         record(payload)
                     elif kind == "dead":
                         self.log(f"replicate worker on GPU {w['gpu']}: {payload}")
-                        bury(conn, "start-up failure")
+                        bury(conn, "start-up failure" if not w["inflight"] else str(payload))
                         continue
                     feed(conn)
                 now = time.time()
+                if retry:
+                    feed_idle()
+                    if retry and not any(w2["ready"] or w2["p"].is_alive() for w2 in workers.values()):
+                        while retry:            # nobody left who could ever take them: error records, not a spin
+                            i = retry.popleft()
+                            if out[i] is None:
+                                record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": -1,
+                                        "error": "no worker process left to retry this unit"})
                 for conn in list(workers):      # belt and braces: a process can be gone before its pipe says so
                     w = workers[conn]
                     if not w["p"].is_alive() and not conn.poll():

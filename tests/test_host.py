@@ -639,3 +639,19 @@ def test_pool_kills_a_worker_whose_host_phase_hangs():
     for i in (0, 1, 3, 4):
         assert "error" not in res[i] and res[i]["value"] == 2 * i, res[i]
     assert any("host work exceeded --unit_timeout" in str(l) for l in logs)
+
+
+def test_pool_reports_a_loader_thread_failure_instead_of_hanging(monkeypatch):
+    """the shared-memory segment a worker is told to attach does not exist (gone, /dev/shm full).
+    The loader thread's failure used to kill only that daemon thread - the process stayed alive, blocked on its queue,
+    and with the default --unit_timeout 0 the run hung.  Now the worker reports ("dead", why) and exits; every unit
+    ends as an error record (each is tried by at most two workers) and the run returns."""
+    import time
+    units = [dict(name=f"s{i}", replicate=i) for i in range(4)]
+    monkeypatch.setattr(R, "_share", lambda shared: ({}, {"big": ("psm_locator_test_no_such_segment", (4,), "<f4")}, []))
+    logs = []
+    t0 = time.time()
+    res = R.run_units(units, _Args(), _slow_fit, n_gpus=1, fits_per_gpu=2, log=logs.append, poll_s=0.1)
+    assert time.time() - t0 < 120
+    assert len(res) == 4 and all(r is not None and "error" in r for r in res), res
+    assert any("loader thread failed" in str(l) for l in logs), logs

@@ -11,10 +11,10 @@ O=$R/gpurun_out
 mkdir -p $O
 rm -rf $O/gp1 $O/gp2 $O/gp3 $O/gp4
 B="python3 $R/tools/rows_gemm_bench.py --rows $ROWS --iters 3 ${GEMM_BENCH_ARGS:---gemm-only}"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $O/gp1 -o p --output-format csv -- $B > $O/gp1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $O/gp2 -o p --output-format csv -- $B > $O/gp2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM -d $O/gp3 -o p --output-format csv -- $B > $O/gp3.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/gp4 -o p --output-format csv -- $B > $O/gp4.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $O/gp1 -o p --output-format csv -- $B > $O/gp1.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU -d $O/gp2 -o p --output-format csv -- $B > $O/gp2.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM -d $O/gp3 -o p --output-format csv -- $B > $O/gp3.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/gp4 -o p --output-format csv -- $B > $O/gp4.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

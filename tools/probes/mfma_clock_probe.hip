@@ -148,9 +148,15 @@ static void run_rate(const char* name, int data, int threads, int iters, int lau
     const double n_mfma = (double)grid * waves * iters * 32.0 * launches;
     const double flops = n_mfma * 32.0 * 32.0 * (MODE == 2 ? 32.0 : 16.0) * 2.0;
     const double ghz = cyc / rt * 0.1;
+    // Mean over WAVES of (a wave's own lifetime in shader cycles / its MFMAs), divided by the waves per SIMD.  This is the
+    // SIMD's issue interval only when the waves of a SIMD share it evenly - it reads 32.0 (= 8 passes x 4 cycles, what
+    // 2.5 PF / 1024 SIMDs / 2.4 GHz implies) with ONE wave per SIMD.  With two waves per SIMD the issue arbiter serves the
+    // older wave first: it runs at 32 cycles per MFMA for its whole life, the younger one gets the gaps and then the SIMD
+    // to itself, so the two lifetimes are T and 2 T, their mean is 48 cycles per MFMA and this column reads 24 - at an
+    // unchanged rate (the `tops` column, which is what the roofline uses).  It is a wave-lifetime statistic, not a pipe rate.
     const double cyc_per_mfma_simd = (cyc / (grid * waves)) / (iters * 32.0) / (waves > 4 ? 2.0 : 1.0);
     printf("{\"probe\": \"mfma_rate\", \"type\": \"%s\", \"data\": \"%s\", \"waves_per_simd\": %d, \"launch_ms\": %.3f, \"launches\": %d, "
-           "\"tops\": %.1f, \"frac_of_2500\": %.3f, \"clock_ghz\": %.3f, \"cycles_per_mfma_per_simd\": %.2f}\n",
+           "\"tops\": %.1f, \"frac_of_2500\": %.3f, \"clock_ghz\": %.3f, \"mean_wave_lifetime_cycles_per_mfma_div_waves_per_simd\": %.2f}\n",
            name, data == 0 ? "zeros" : data == 1 ? "genotype A, random B" : "random", waves / 4, ms / launches, launches,
            flops / (ms * 1e-3) * 1e-12, flops / (ms * 1e-3) * 1e-12 / 2500.0, ghz, cyc_per_mfma_simd);
     fflush(stdout);

@@ -24,7 +24,7 @@ python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/${TA
 python3 bench.py --steps 50 --warmup 5 --replicates-per-gpu 2 --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_replicates2.json 2>> $O/${TAG}_bench_default.err
 python3 bench.py --gpus 2 --device-index 0 --dist-backend gloo --steps 20 --warmup 5 > $O/${TAG}_bench_2ranks_selflaunch.json 2>> $O/${TAG}_bench_default.err
 cd /tmp
-rm -rf $O/prof_kt
+rm -rf $O/prof_kt; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/prof_kt -o k --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled.json 2> $O/prof_kt.err
 cp $O/prof_kt/k_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
 bash $R/tools/chain_pmc.sh > $O/chain_pmc.log 2>&1               # counters of the chained layer-1 kernel alone
