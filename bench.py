@@ -360,6 +360,9 @@ def main():
     ap.add_argument("--no-l1-gemm", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
+    ap.add_argument("--sync-epochs", action="store_true",
+                    help="measurement switch: wait for every epoch before enqueueing the next (FitLoop depth 0) instead of "
+                         "running two epochs ahead of the device")
     ap.add_argument("--lib", default=None, help="measurement switch: another build of liblocator_hip.so (make ablate_chain ...)")
     ap.add_argument("--no-chain", action="store_true",
                     help="measurement switch: one layer-1 forward launch per step instead of chaining it into the "
@@ -403,7 +406,7 @@ def main():
     from locator_amd import _lib
     from locator_amd.net import LocatorNet, gather_columns, upload_genotypes
     from locator_amd.synth import normalize_locs, split_indices, synth_genotypes
-    from locator_amd.train import Callbacks, EpochRunner
+    from locator_amd.train import FitLoop
 
     K, H, n, R = args.snps, args.width, args.n, max(1, args.replicates_per_gpu)
     x, locs = synth_genotypes(n, K, seed=20260101, n_na=n // 10)
@@ -428,28 +431,28 @@ def main():
                                          ({"stack_helpers": args.stack_helpers} if args.stack_helpers else {}))
             if args.l1_bwd_grid:
                 self.net.l1_bwd_grid = int(args.l1_bwd_grid)
-            self.runner = EpochRunner(self.net, train, test, args.batch, use_graph=not args.no_graph,
-                                      chain=False if args.no_chain else None)
-            self.cb = Callbacks(100, 1e-3)
+            # the product's epoch loop (locator_amd/train.py FitLoop): callbacks on the device, epochs enqueued ahead of it.
+            # Early stopping is parked (patience 10^6) so that exactly --steps epochs are timed; checkpoint copies and the
+            # LR plateau (patience 16 = int(100 / 6), locator.py:354) are live.
             self.rng = np.random.default_rng(99 + replicate)
+            self.loop = FitLoop(self.net, train, test, batch_size=args.batch, max_epochs=args.steps + max(args.warmup, 2) + 64, patience=10 ** 6,
+                                lr_patience=16, use_graph=not args.no_graph, chain=False if args.no_chain else None,
+                                perm_fn=lambda e: self.rng.permutation(len(train)), depth=0 if args.sync_epochs else 2)
+            self.runner = self.loop.runner
             self.stream = torch.cuda.Stream(device=dev) if R > 1 else torch.cuda.current_stream()
-            self.hist = []
-            self.e = 0
+
+        @property
+        def hist(self):
+            h = self.loop.hist.history
+            return list(zip(h["loss"], h["val_loss"]))
 
         def start(self, ev=None):
             with torch.cuda.stream(self.stream):
-                self.runner.start_epoch(self.rng.permutation(self.runner.n_train), ev)
+                self.loop.submit(ev)
 
-        def finish(self):
+        def finish(self, lag=None):
             with torch.cuda.stream(self.stream):
-                loss, val = self.runner.finish_epoch()
-                save, stop, lr_logged = self.cb.on_epoch_end(self.e, val)
-                if save:
-                    self.net.snapshot()
-                if self.cb.lr != lr_logged:
-                    self.net.lr_t.fill_(self.cb.lr)
-            self.hist.append((loss, val))
-            self.e += 1
+                self.loop.collect(lag)
 
     fits = [Fit(rank * R + r) for r in range(R)]
     torch.cuda.synchronize()
@@ -459,7 +462,11 @@ def main():
         for f in fits:
             f.start(ev)
         for f in fits:
-            f.finish()
+            f.finish(0 if ev is not None else None)        # instrumented epochs are read back at once
+
+    def drain():
+        for f in fits:
+            f.finish(0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -470,10 +477,12 @@ def main():
     warm = max(args.warmup, 2)                 # epoch 0 eager, epoch 1 captures the graph
     for _ in range(warm):
         epoch()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         epoch()
+    drain()                                    # every timed epoch's history row has been read back
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -499,7 +508,7 @@ def main():
             pairs = [(evs[2 * (k * steps_per_epoch + j)], evs[2 * (k * steps_per_epoch + j) + 1])
                      for j in range(steps_per_epoch)]
             f0.start(pairs)
-            f0.finish()
+            f0.finish(0)
             for j, (a, b) in enumerate(pairs):
                 o = C.c_float()
                 _lib.check(lib.loc_event_elapsed_ms(a, b, C.byref(o)))
@@ -533,10 +542,11 @@ def main():
             "config": {"workload": f"synthetic {n} ind x {K} SNPs uint8 (BASELINE.json configs[2]), "
                                    f"{'single model fit' if R == 1 else str(R) + ' concurrent replicate fits'} per GPU, "
                                    f"batch {args.batch}, {n_train} train / {len(test)} validation",
-                       "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + callbacks"
+                       "step": f"one epoch = {steps_per_epoch} minibatch steps + validation sweep + device-side callbacks + checkpoint copy"
                                + ("" if R == 1 else f", of each of the {R} fits"),
                        "width": H, "nlayers": 10, "graph": not args.no_graph,
-                       "chained_steps": bool(fits[0].runner.chain), "replicates_per_gpu": R,
+                       "chained_steps": bool(fits[0].runner.chain), "epochs_in_flight": 0 if args.sync_epochs else 2,
+                       "replicates_per_gpu": R,
                        "replicates": ("single model" if world == 1 and R == 1 else
                                       f"{R} model(s) per GPU, bootstrap resample per replicate")},
             "us_per_minibatch_step": round(ms_epoch * 1e3 / steps_per_epoch / R, 2),

@@ -150,8 +150,23 @@ typedef struct loc_net {
                                 When set, row chunks of at least LOC_GEMM_I8_PACKED_MIN_ROWS rows of an int8 many-row predict
                                 read it instead of X (a quarter of the genotype traffic, bit-identical activations)        */
     int64_t x2_pitch;
+    int l1_scan_ready;       /* != 0: the header of l1_image already holds loc_l1_quant_scan's per-unit maxima for the CURRENT
+                                parameters (loc_predict_scan ran since they last changed): loc_predict's int8 image build skips
+                                that pass over W1 */
     loc_tuning tune;
 } loc_net;
+/* Dynamic-range guard of the int8 digit image (loc_l1_quant_scan).  R_h = max_k |w'| / (1.2533 mean_k |w'|) for unit h, w' =
+ * BatchNorm scale x first-layer weight: the largest weight over the rms of a Gaussian bulk with the unit's mean magnitude
+ * (the mean, not the rms, so that a single huge weight cannot hide by inflating the yardstick).
+ *   two digit planes (16-bit fixed point against the unit's largest weight) while  median_h R_h <= LOC_GUARD_FAST_MEDIAN and
+ *   max_h R_h <= LOC_GUARD_FAST_MAX  - a typical weight then keeps >= 9 bits (6 at the worst unit);
+ *   three planes (24 bits) while  max_h R_h <= LOC_GUARD_EXACT_MAX  - >= 14 bits for a typical weight, the "no worse than an
+ *   fp32 accumulation" regime;
+ *   otherwise the weights go through the bf16 x 3 pieces, exact for any fp32 weight.
+ * Measured deviations of the predictions from the float64 forward per regime: tests/test_gpu_trained_predict.py, DESIGN.md. */
+#define LOC_GUARD_FAST_MEDIAN 64.0f
+#define LOC_GUARD_FAST_MAX 512.0f
+#define LOC_GUARD_EXACT_MAX 512.0f
 /* Rows from which the int8 image + GEMM beats the in-loop-conversion bf16x3 kernel including its once-per-call max pass
  * and conversion (K = 100,000, profiles/r03_gemm_bench.json). */
 #define LOC_GEMM_I8_MIN_ROWS(digits) 512
@@ -273,6 +288,16 @@ int loc_l1_gemm_i8_supported(int Hp, int digits);
 int64_t loc_l1_image_i8_bytes(const loc_dims* d, int digits);
 int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
                           void* stream);
+/* The first pass of loc_l1_image_i8_build on its own: per-unit max_k |s_k W1[k][h]| into the image header, and the
+ * dynamic-range guard computed from it and the per-unit rms in the same pass over W1: four floats at byte offset
+ * loc_l1_image_i8_guard_offset() of `image` = { median_h R_h, max_h R_h, digit planes the guard allows (2, 3, or -1: none -
+ * use the bf16 x 3 pieces), the same when the caller insists on the exact mode (3 or -1) }.  image: at least
+ * loc_l1_image_i8_bytes(d, 2) bytes.  loc_l1_image_i8_build_scanned = loc_l1_image_i8_build without that pass (the header
+ * must hold a scan of the same weights and scale/shift). */
+int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, void* stream);
+int64_t loc_l1_image_i8_guard_offset(void);
+int loc_l1_image_i8_build_scanned(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
+                                  void* stream);
 int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                            const void* image, int digits, int x_max, const float* b1, float* partial,
                            int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune, void* stream);
@@ -414,6 +439,12 @@ float* loc_workspace_bn4(const loc_net* net);
 int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets, float* dist,
                 void* stream);
 
+/* What a caller that lets the guard choose the digit planes runs before loc_predict when the parameters have changed:
+ * BatchNorm inference scale/shift into the workspace, then loc_l1_quant_scan on net->l1_image (needs
+ * loc_l1_image_i8_bytes(d, 2) bytes there).  The caller reads the four guard floats back (the one synchronising step of a
+ * many-row predict), sets net->predict_digits / predict_pieces accordingly and net->l1_scan_ready = 1. */
+int loc_predict_scan(const loc_net* net, void* stream);
+
 /* Which weight image loc_predict builds and uses for n rows of this net: 0 = none (in-loop conversion or the 32-row
  * kernels), 1..3 = bf16 pieces (loc_l1_image_build), 12 / 13 = int8 with 2 / 3 digit planes (loc_l1_image_i8_build). */
 int loc_predict_image_mode(const loc_net* net, int n);
@@ -428,6 +459,49 @@ int loc_pack_genotypes_2bit(const uint8_t* X, int64_t x_pitch, int n_rows, int K
 int loc_l1_forward_gemm_i8_packed(const uint8_t* X2, int64_t x2_pitch, const int32_t* rows, int n, const loc_dims* d,
                                   const void* image, int digits, const float* b1, float* partial, int64_t partial_floats,
                                   float* a1, int target_blocks, const loc_tuning* tune, void* stream);
+
+/* ---- filter_snps + the split's transposes on the device, for the --windows loop (locator.py:265-273, :295-308, :539-545) ----
+ * gt: the window's calls as the zarr store holds them, int8 [n_variants][n_samples][ploidy] (negative = missing).
+ * loc_filter_snps_flags: keep[v] = 1 iff exactly two distinct alleles occur at variant v (allel's is_biallelic of
+ * count_alleles) and - unless min_mac == 1, when the reference skips that filter - allele 1 occurs at least min_mac times;
+ * pos = exclusive prefix sum of keep, *n_kept = their number (the SNP count K of the window's model).
+ * loc_filter_snps_rows: X[r][pos[v]] = number of allele-1 copies of sample sample_order[r] at kept variant v
+ * (to_allele_counts()[:, :, 1] transposed and row-gathered: `ac[:, rows].T`), r < n_out; X is [n_out][x_pitch] uint8 and must
+ * be zeroed beyond K by the caller.  No --impute_missing / --max_SNPs here (both consume the NumPy stream: host path). */
+int loc_filter_snps_flags(const int8_t* gt, int64_t n_variants, int n_samples, int ploidy, int min_mac, uint8_t* keep,
+                          int32_t* pos, int32_t* n_kept, void* stream);
+int loc_filter_snps_rows(const int8_t* gt, int64_t n_variants, int n_samples, int ploidy, const uint8_t* keep,
+                         const int32_t* pos, const int32_t* sample_order, int n_out, uint8_t* X, int64_t x_pitch, void* stream);
+
+/* ---- the three callbacks of a fit, on the device (locator.py:330-362) ----
+ * State of ModelCheckpoint(best only) -> EarlyStopping -> ReduceLROnPlateau, all on val_loss, strict '<', min_delta 0.
+ * The host fills it once (bests = +inf, waits 0, lr = the fit's starting rate, epoch 0, stopped 0, stop_epoch / best_epoch
+ * -1) and uploads it; loc_epoch_callbacks, enqueued after the validation sweep of every epoch, does what the three
+ * on_epoch_end calls do, and loc_snapshot_if copies params -> best when that epoch improved val_loss.  With these two in
+ * the epoch's stream (or captured graph) the host can enqueue epochs ahead of the device and read the history rows with
+ * a lag (locator_amd/train.py); once early stopping has fired the state, the LR and `best` are frozen, so epochs already
+ * enqueued behind the stop epoch are harmless and their rows are dropped. */
+typedef struct loc_cb_state {
+    double ck_best, es_best, rl_best; /* best val_loss seen by each callback                                            */
+    float lr;                         /* current learning rate (fp32, as Keras keeps it); mirrored into *lr             */
+    float lr_factor;                  /* ReduceLROnPlateau factor (0.5, locator.py:352)                                 */
+    int es_wait, rl_wait;
+    int patience, lr_patience;        /* --patience; int(patience / 6) (locator.py:343, :354)                           */
+    int epoch;                        /* epochs completed                                                               */
+    int stopped;                      /* 1 once EarlyStopping fired                                                     */
+    int stop_epoch;                   /* index of that epoch, or -1                                                     */
+    int best_epoch;                   /* index of the epoch whose weights `best` holds, or -1                           */
+    int save_now;                     /* 1 between loc_epoch_callbacks and loc_snapshot_if of an improving epoch        */
+    int reserved;
+} loc_cb_state;
+/* stats: the epoch's `steps` per-minibatch losses followed by its n_val validation distances (what loc_train_step* and
+ * loc_predict(with_targets) wrote); the last minibatch has n_last rows, the others `batch`.  Writes hist[4 * epoch ..] =
+ * { loss, val_loss, learning rate the epoch trained with, flags: 1 = checkpoint saved, 2 = early stopping fired, 4 = LR
+ * reduced } for epoch < hist_cap, unless early stopping fired at an earlier epoch. */
+int loc_epoch_callbacks(const float* stats, int steps, int batch, int n_last, int n_val, loc_cb_state* state, float* lr,
+                        double* hist, int hist_cap, void* stream);
+/* params -> best (n floats, n % 4 == 0, 16-byte aligned) iff state->save_now. */
+int loc_snapshot_if(const loc_cb_state* state, const float* params, float* best, int64_t n, void* stream);
 
 /* thin event helpers so a ctypes host can time a kernel on the stream it runs on */
 int loc_event_create(void** ev);

@@ -48,7 +48,14 @@ class Net(C.Structure):
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
                 ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
                 ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("x_max", C.c_int), ("predict_digits", C.c_int),
-                ("l1_image_ready", C.c_int), ("X2", vp), ("x2_pitch", C.c_int64), ("tune", Tuning)]
+                ("l1_image_ready", C.c_int), ("X2", vp), ("x2_pitch", C.c_int64), ("l1_scan_ready", C.c_int), ("tune", Tuning)]
+
+
+class CbState(C.Structure):
+    _fields_ = [("ck_best", C.c_double), ("es_best", C.c_double), ("rl_best", C.c_double), ("lr", C.c_float),
+                ("lr_factor", C.c_float), ("es_wait", C.c_int), ("rl_wait", C.c_int), ("patience", C.c_int),
+                ("lr_patience", C.c_int), ("epoch", C.c_int), ("stopped", C.c_int), ("stop_epoch", C.c_int),
+                ("best_epoch", C.c_int), ("save_now", C.c_int), ("reserved", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/locator_hip.h one to one
@@ -86,6 +93,10 @@ SIGNATURES = {
     "loc_l1_gemm_i8_supported": (C.c_int, [C.c_int, C.c_int]),
     "loc_l1_image_i8_bytes": (C.c_int64, [C.POINTER(Dims), C.c_int]),
     "loc_l1_image_i8_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
+    "loc_l1_quant_scan": (C.c_int, [C.POINTER(Dims), vp, vp, vp, vp]),
+    "loc_l1_image_i8_guard_offset": (C.c_int64, []),
+    "loc_l1_image_i8_build_scanned": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
+    "loc_predict_scan": (C.c_int, [C.POINTER(Net), vp]),
     "loc_l1_forward_gemm_i8": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp, vp,
                                          C.c_int64, vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_genotype_max": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
@@ -126,6 +137,10 @@ SIGNATURES = {
                                                 vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_predict": (C.c_int, [C.POINTER(Net), vp, C.c_int, vp, C.c_int, vp, vp]),
     "loc_predict_image_mode": (C.c_int, [C.POINTER(Net), C.c_int]),
+    "loc_filter_snps_flags": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "loc_filter_snps_rows": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int64, vp]),
+    "loc_epoch_callbacks": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "loc_snapshot_if": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
     "loc_event_create": (C.c_int, [C.POINTER(vp)]),
     "loc_event_destroy": (C.c_int, [vp]),
     "loc_event_record": (C.c_int, [vp, vp]),

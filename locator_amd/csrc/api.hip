@@ -322,6 +322,20 @@ extern "C" int loc_predict_image_mode(const loc_net* net, int n) {
     return 0;
 }
 
+extern "C" int loc_predict_scan(const loc_net* net, void* stream) {
+    const loc_dims* d = &net->d;
+    if (!net->l1_image || net->l1_image_bytes < loc_l1_image_i8_bytes(d, 2)) {
+        loc_set_error("loc_predict_scan: net->l1_image must hold loc_l1_image_i8_bytes(d, 2) bytes");
+        return -1;
+    }
+    loc_layout lay;
+    loc_param_layout(d, &lay);
+    const float* P = net->params;
+    ws_view w = carve(d, net->ws, 0, LOC_ROWS, slot_cap_of(net));
+    TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
+    return loc_l1_quant_scan(d, w.bn4, P + lay.w1, net->l1_image, stream);
+}
+
 extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float* yhat, int with_targets,
                            float* dist, void* stream) {
     if (n <= 0) return 0;
@@ -344,7 +358,8 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         const int mode = loc_predict_image_mode(net, n);
         const bool i8 = mode >= 12, gemm = mode >= 1 && mode <= 3;
         if (mode && net->l1_image_ready != mode) {
-            if (i8) TRY(loc_l1_image_i8_build(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
+            if (i8 && net->l1_scan_ready) TRY(loc_l1_image_i8_build_scanned(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
+            else if (i8) TRY(loc_l1_image_i8_build(d, w.bn4, P + lay.w1, digits, net->l1_image, stream));
             else TRY(loc_l1_image_build(d, w.bn4, P + lay.w1, pieces, net->l1_image, stream));
         }
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {

@@ -60,26 +60,83 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 // per unit and workgroup at the end (a few hundred workgroups, not one per block: the atomics all hit the same 256
 // words).  colmax[n] = max |s_k W1[k][n]| as the bit pattern of a non-negative float: the maximum is order-independent,
 // so the result is deterministic.
+// The same pass also leaves sumabs_part[workgroup][n] = this workgroup's share of sum_k |w'| (fixed order inside a
+// workgroup; l1_quant_guard_kernel adds the shares in workgroup order): the unit's TYPICAL weight, against which its
+// largest weight decides how many digit planes the weights need (dynamic range guard below).  The mean magnitude, not
+// the rms: one weight 3000 x the rest moves the rms of 100,000 weights by 10 x (max / rms can never exceed sqrt(K), and
+// the first version of this guard, built on the rms, let exactly that case through) but the mean by 3 %.
 __global__ __launch_bounds__(G8_HP) void l1_colmax_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
-                                                          int Kp, int nkt64, uint32_t* __restrict__ colmax) {
+                                                          int Kp, int nkt64, uint32_t* __restrict__ colmax,
+                                                          float* __restrict__ sumabs_part) {
     constexpr int nht = G8_HP / 32;
     const int n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
-    float mx = 0.f;
+    float mx = 0.f, ss = 0.f;
     for (int kt64 = blockIdx.x; kt64 < nkt64; kt64 += gridDim.x) {
 #pragma unroll
         for (int h32 = 0; h32 < 2; ++h32) {
             const int kt32 = 2 * kt64 + h32;
             if (kt32 * 32 < Kp) {
                 const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128 + c4;
-                float m4[4] = {0.f, 0.f, 0.f, 0.f};
+                float m4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kl = 0; kl < 32; ++kl) m4[kl & 3] = fmaxf(m4[kl & 3], fabsf(src[kl * 4] * ss4[kt32 * 32 + kl]));
+                for (int kl = 0; kl < 32; ++kl) {
+                    const float w = src[kl * 4] * ss4[kt32 * 32 + kl];
+                    m4[kl & 3] = fmaxf(m4[kl & 3], fabsf(w));
+                    s4[kl & 3] += fabsf(w);
+                }
                 mx = fmaxf(mx, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+                ss += (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
         }
     }
     if (mx > 0.f) atomicMax(colmax + n, fbits(mx));
+    sumabs_part[(int64_t)blockIdx.x * G8_HP + n] = ss;
+}
+
+// Dynamic-range guard of the fixed-point image.  A unit's weights share one power-of-two step delta_h chosen from its
+// LARGEST |w'|, so what a digit count leaves for a typical weight is set by R_h = max_k |w'| / (1.2533 mean_k |w'|) - the
+// largest weight over the rms a Gaussian bulk of that mean magnitude would have: a typical weight keeps
+// log2(2^(8 D - 1) / R_h) bits and its quantisation noise is R_h 2^-(8 D - 1) / sqrt(12) of its size.  After training the
+// ratio is a few tens (rare SNPs carry BatchNorm scales up to 30 x the common ones, Adam grows informative rows;
+// tools/quant_study.py, tests/test_gpu_trained_predict.py), which two digits carry with a measured deviation of 5e-5 on the
+// predictions; a weight 1000 x its unit's typical size takes two digits to 2.5e-3 and three to 1e-5.
+// guard[0] = median R over the real units (lower middle value), guard[1] = largest R, guard[2] = digit planes that hold
+// the tolerances of include/locator_hip.h (LOC_GUARD_*): 2, 3, or -1 = not even three (bf16 x 3 pieces: exact for any
+// weights), guard[3] = 3 or -1: the same decision when the caller insists on the exact mode.
+__global__ __launch_bounds__(G8_HP) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
+                                                               const float* __restrict__ sumabs_part, int nparts, int K, int H,
+                                                               float* __restrict__ guard) {
+    __shared__ float R[G8_HP];
+    const int n = threadIdx.x;
+    float ss = 0.f;
+    for (int b = 0; b < nparts; ++b) ss += sumabs_part[(int64_t)b * G8_HP + n];
+    const float mx = bitsf(colmax[n]);
+    const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
+    const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
+    R[n] = r;
+    __syncthreads();
+    // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
+    int rank = 0;
+    for (int j = 0; j < H; ++j) rank += (R[j] < r || (R[j] == r && j < n)) ? 1 : 0;
+    __shared__ float red[G8_HP];
+    red[n] = r;
+    __syncthreads();
+    for (int o = G8_HP / 2; o > 0; o >>= 1) {
+        if (n < o) red[n] = fmaxf(red[n], red[n + o]);
+        __syncthreads();
+    }
+    __shared__ float s_med;
+    if (n < H && rank == (H - 1) / 2) s_med = r;
+    __syncthreads();
+    if (n == 0) {
+        const float rmed = s_med, rmax = red[0];
+        guard[0] = rmed;
+        guard[1] = rmax;
+        const float exact = rmax <= LOC_GUARD_EXACT_MAX ? 3.f : -1.f;
+        guard[2] = (rmed <= LOC_GUARD_FAST_MEDIAN && rmax <= LOC_GUARD_FAST_MAX) ? 2.f : exact;
+        guard[3] = exact;
+    }
 }
 
 // delta_h = 2^e with max_k|w'| / delta_h inside the signed-digit range: 127 (256^DT - 1) / 255.
@@ -534,10 +591,13 @@ static int g8_nkt64(const loc_dims* d) { return ((d->Kp + G8_BK - 1) / G8_BK + 1
 
 extern "C" int loc_l1_gemm_i8_supported(int Hp, int digits) { return Hp == G8_HP && (digits == 2 || digits == 3); }
 
-// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][cpart: nkt64*Hp floats][tiles], 1 KB aligned sections
+// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][guard: Hp floats, 4 used][cpart: nkt64*Hp floats][tiles],
+// 1 KB aligned sections.  The scan (colmax + guard) borrows the cpart section for its per-workgroup sums of squares; the
+// image kernel overwrites it afterwards.
 static int64_t g8_delta_off() { return 8 * G8_HP * 4; }
 static int64_t g8_colmax_off() { return g8_delta_off() + G8_HP * 4; }
-static int64_t g8_cpart_off() { return g8_colmax_off() + G8_HP * 4; }
+static int64_t g8_guard_off() { return g8_colmax_off() + G8_HP * 4; }
+static int64_t g8_cpart_off() { return g8_guard_off() + G8_HP * 4; }
 static int64_t g8_tiles_off(const loc_dims* d) {
     return (g8_cpart_off() + (int64_t)g8_nkt64(d) * G8_HP * 4 + 1023) / 1024 * 1024;
 }
@@ -546,8 +606,27 @@ extern "C" int64_t loc_l1_image_i8_bytes(const loc_dims* d, int digits) {
     return g8_tiles_off(d) + (int64_t)g8_nkt64(d) * digits * G8_TILE;
 }
 
-extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits,
-                                     void* image, void* stream) {
+// colmax + per-unit rms -> guard (see l1_quant_guard_kernel); the image kernels read colmax from the same header
+extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, void* stream) {
+    if (d->Hp != G8_HP) { loc_set_error("loc_l1_quant_scan: needs padded width 256 (got %d)", d->Hp); return -1; }
+    unsigned char* base = static_cast<unsigned char*>(image);
+    uint32_t* colmax = reinterpret_cast<uint32_t*>(base + g8_colmax_off());
+    float* guard = reinterpret_cast<float*>(base + g8_guard_off());
+    float* cpart = reinterpret_cast<float*>(base + g8_cpart_off());
+    const int nkt = g8_nkt64(d), grid = nkt < 512 ? nkt : 512;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
+    if (e != hipSuccess) { loc_set_error("loc_l1_quant_scan: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(l1_colmax_kernel, dim3(grid), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax, cpart);
+    LOC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l1_quant_guard_kernel, dim3(1), dim3(G8_HP), 0, st, colmax, cpart, grid, d->K, d->H, guard);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int64_t loc_l1_image_i8_guard_offset(void) { return g8_guard_off(); }
+
+static int g8_image_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
+                          bool scanned, void* stream) {
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) {
         loc_set_error("loc_l1_image_i8_build: width %d / %d digits unsupported (needs padded width 256, 2 or 3 digits)",
                       d->Hp, digits);
@@ -561,16 +640,24 @@ extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift
     unsigned char* tiles = base + g8_tiles_off(d);
     const int nkt = g8_nkt64(d);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
-    if (e != hipSuccess) { loc_set_error("loc_l1_image_i8_build: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(l1_colmax_kernel, dim3(nkt < 512 ? nkt : 512), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax);
-    LOC_CHECK_LAUNCH();
+    if (!scanned) {
+        const int rc = loc_l1_quant_scan(d, scale_shift, w1s, image, stream);
+        if (rc) return rc;
+    }
     if (digits == 2)
         hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax, delta, tiles, cpart);
     else
         hipLaunchKernelGGL(l1_image_i8_kernel<3>, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax, delta, tiles, cpart);
     LOC_CHECK_LAUNCH();
     return gm_launch_cvec(cpart, nkt, cvec, stream);
+}
+extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits,
+                                     void* image, void* stream) {
+    return g8_image_build(d, scale_shift, w1s, digits, image, false, stream);
+}
+extern "C" int loc_l1_image_i8_build_scanned(const loc_dims* d, const float* scale_shift, const float* w1s, int digits,
+                                             void* image, void* stream) {
+    return g8_image_build(d, scale_shift, w1s, digits, image, true, stream);
 }
 
 static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d, const void* image,

@@ -188,3 +188,103 @@ extern "C" int loc_w1_unswizzle(const float* w1s, int Kp, int Hp, float* w_kh, i
     LOC_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The three Keras callbacks of a fit on the device (locator.py:330-362), so that model.fit's epoch loop
+// (locator.py:367-376) needs no host round trip between epochs: nothing that decides the NEXT epoch's work depends on
+// the host - permutations and dropout masks are callback-independent, and ModelCheckpoint / EarlyStopping /
+// ReduceLROnPlateau are three comparisons of one scalar.
+// ---------------------------------------------------------------------------------------------------------
+// One workgroup.  loss = sum_j loss_j n_j / n_train (what Keras logs: the sample-weighted mean of the per-step losses),
+// val_loss = mean of the validation distances; both summed in double, in index order.  Then, in the callback list's order
+// (locator.py:362): checkpoint (strict <), early stopping (wait += 1 first; fires on wait >= patience and epoch > 0),
+// LR plateau (strict <, else wait += 1 and on wait >= patience: lr <- max(lr * factor, 0) in fp32, wait <- 0).  The LR
+// logged for an epoch is the one it trained with.  Once early stopping has fired the state is frozen: later epochs that
+// the host had already enqueued change neither the best weights nor the LR nor the history rows the host keeps.
+__global__ __launch_bounds__(256) void epoch_callbacks_kernel(const float* __restrict__ stats, int steps, int batch, int n_last,
+                                                              int n_val, loc_cb_state* __restrict__ st, float* __restrict__ lr,
+                                                              double* __restrict__ hist, int hist_cap) {
+    __shared__ float buf[1024];
+    const int t = threadIdx.x;
+    const int n_train = (steps - 1) * batch + n_last;
+    double loss = 0.0, val = 0.0;
+    // stage through LDS in chunks of 1024 values; thread 0 adds them up in index order (a few hundred values per epoch)
+    for (int base = 0; base < steps; base += 1024) {
+        const int m = steps - base < 1024 ? steps - base : 1024;
+        __syncthreads();
+        for (int i = t; i < m; i += 256) buf[i] = stats[base + i];
+        __syncthreads();
+        if (t == 0)
+            for (int i = 0; i < m; ++i) loss += (double)buf[i] * (double)(base + i == steps - 1 ? n_last : batch);
+    }
+    for (int base = 0; base < n_val; base += 1024) {
+        const int m = n_val - base < 1024 ? n_val - base : 1024;
+        __syncthreads();
+        for (int i = t; i < m; i += 256) buf[i] = stats[steps + base + i];
+        __syncthreads();
+        if (t == 0)
+            for (int i = 0; i < m; ++i) val += (double)buf[i];
+    }
+    if (t != 0) return;
+    loss /= (double)n_train;
+    val /= (double)n_val;
+    const int epoch = st->epoch;
+    st->epoch = epoch + 1;
+    st->save_now = 0;
+    if (st->stopped) return;
+    const float lr_logged = st->lr;
+    int flags = 0;
+    if (val < st->ck_best) { st->ck_best = val; st->save_now = 1; st->best_epoch = epoch; flags |= 1; }
+    st->es_wait += 1;
+    if (val < st->es_best) { st->es_best = val; st->es_wait = 0; }
+    if (st->es_wait >= st->patience && epoch > 0) { st->stopped = 1; st->stop_epoch = epoch; flags |= 2; }
+    if (val < st->rl_best) {
+        st->rl_best = val;
+        st->rl_wait = 0;
+    } else {
+        st->rl_wait += 1;
+        if (st->rl_wait >= st->lr_patience) {
+            const float nl = fmaxf(st->lr * st->lr_factor, 0.0f);
+            st->lr = nl;
+            *lr = nl;
+            st->rl_wait = 0;
+            flags |= 4;
+        }
+    }
+    if (epoch < hist_cap) {
+        double* row = hist + 4 * (int64_t)epoch;
+        row[0] = loss; row[1] = val; row[2] = (double)lr_logged; row[3] = (double)flags;
+    }
+}
+
+// ModelCheckpoint's save as a predicated device copy: every workgroup reads the flag the callback kernel left.
+__global__ __launch_bounds__(256) void snapshot_if_kernel(const loc_cb_state* __restrict__ st, const f32x4* __restrict__ src,
+                                                          f32x4* __restrict__ dst, int64_t n4) {
+    if (!st->save_now) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+extern "C" int loc_epoch_callbacks(const float* stats, int steps, int batch, int n_last, int n_val, loc_cb_state* state,
+                                   float* lr, double* hist, int hist_cap, void* stream) {
+    if (steps < 1 || batch < 1 || n_last < 1 || n_last > batch || n_val < 1 || !state || !lr || !hist) {
+        loc_set_error("loc_epoch_callbacks: steps=%d batch=%d n_last=%d n_val=%d (all >= 1, n_last <= batch)", steps, batch,
+                      n_last, n_val);
+        return -1;
+    }
+    hipLaunchKernelGGL(epoch_callbacks_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, steps, batch, n_last, n_val,
+                       state, lr, hist, hist_cap);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int loc_snapshot_if(const loc_cb_state* state, const float* params, float* best, int64_t n, void* stream) {
+    if (n % 4 || ((uintptr_t)params & 15) || ((uintptr_t)best & 15)) {
+        loc_set_error("loc_snapshot_if: needs 16-byte aligned buffers and a multiple of 4 floats");
+        return -1;
+    }
+    hipLaunchKernelGGL(snapshot_if_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, state,
+                       reinterpret_cast<const f32x4*>(params), reinterpret_cast<f32x4*>(best), n / 4);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

@@ -353,6 +353,56 @@ class ZarrArray:
             rec([], grid)
         return out
 
+    def read_into(self, out, start, stop, threads=4):
+        """out[...] = self[start:stop] for a caller-owned array (e.g. a view of pinned memory that is uploaded as it is:
+        the --windows loop, locator.py:539).  Uncompressed chunks that span the trailing axes are read straight from the
+        file into `out` (one copy, page cache -> destination); compressed chunks are decoded on `threads` threads (the
+        C codecs release the GIL) and copied in."""
+        start, stop, _ = slice(start, stop).indices(self.shape[0])
+        n0 = max(stop - start, 0)
+        if tuple(out.shape) != (n0,) + tuple(self.shape[1:]) or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise ValueError("read_into: `out` must be a C-contiguous array of the slice's shape and dtype")
+        if n0 == 0:
+            return out
+        c0 = self.chunks[0]
+        whole = tuple(self.chunks[1:]) == tuple(self.shape[1:]) and self.order == "C" and not self.vlen_utf8
+        if not whole:
+            out[...] = self[start:stop]
+            return out
+        row = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        flat = out.reshape(n0, -1).view(np.uint8).reshape(-1)
+        tail = (0,) * (self.ndim - 1)
+
+        def one(ci):
+            lo, hi = max(start, ci * c0), min(stop, (ci + 1) * c0)
+            dst = memoryview(flat)[(lo - start) * row:(hi - start) * row]
+            fn = os.path.join(self.path, self.sep.join(str(i) for i in (ci,) + tail))
+            if not os.path.exists(fn):
+                np.frombuffer(dst, dtype=np.uint8)[...] = 0 if self.fill_value is None else self.fill_value
+            elif self.compressor is None:
+                with open(fn, "rb", buffering=0) as fh:
+                    fh.seek((lo - ci * c0) * row)
+                    got, want = 0, len(dst)
+                    while got < want:
+                        k = fh.readinto(dst[got:])
+                        if not k:
+                            raise IOError(f"{fn}: chunk shorter than its shape")
+                        got += k
+            else:
+                with open(fn, "rb") as fh:
+                    ch = self._decode(fh.read(), self.chunks)
+                np.frombuffer(dst, dtype=self.dtype).reshape((hi - lo,) + tuple(self.shape[1:]))[...] = ch[lo - ci * c0:hi - ci * c0]
+
+        cis = list(range(start // c0, (stop - 1) // c0 + 1))
+        if len(cis) > 1 and threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(min(threads, len(cis))) as ex:
+                list(ex.map(one, cis))
+        else:
+            for ci in cis:
+                one(ci)
+        return out
+
     def __array__(self, dtype=None, copy=None):
         a = self[:]
         return a.astype(dtype) if dtype is not None else a

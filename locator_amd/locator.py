@@ -82,6 +82,9 @@ def build_parser():
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
     p.add_argument("--fits_per_gpu", default=2, type=int,
                    help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
+    p.add_argument("--host_filter", default=False, action="store_true",
+                   help="--windows: filter each window's SNPs on the host (NumPy) as rounds 1-3 did, instead of uploading "
+                        "the raw calls and filtering on the device (same rows bit for bit; measurement / fallback switch)")
     p.add_argument("--unit_timeout", default=0, type=float,
                    help="seconds one --windows / --bootstrap replicate may take inside a worker before that worker is "
                         "killed and replaced and the replicate reported as failed (default 0: no limit)")
@@ -91,14 +94,19 @@ def build_parser():
                         "layer-1 backward (the round-2 schedule; same results up to fp32 round-off, about 10 %% slower)")
     p.add_argument("--load_weights", default=None, type=str,
                    help="a .weights.npz written by --keep_weights: skip training and predict with these weights")
-    p.add_argument("--predict_mode", default="exact", choices=("exact", "fast"),
-                   help="first-layer arithmetic of many-row predictions on the int8 matrix pipe: exact = 24-bit fixed "
-                        "point per weight (as accurate as fp32 accumulation; default), fast = 16-bit (predictions "
-                        "within 1e-3 relative, tests/test_gpu_baseline_sizes.py)")
-    p.add_argument("--predict_packed", default=False, action="store_true",
-                   help="keep a 2-bit packed copy of every genotype matrix that is predicted from (values 0..3 only): "
-                        "predictions over 3072 rows or more then read a quarter of the genotype bytes, with identical "
-                        "results; pays when the same matrix is predicted from repeatedly (packing is one extra pass)")
+    p.add_argument("--predict_mode", default="auto", choices=("auto", "exact", "fast"),
+                   help="first-layer arithmetic of many-row predictions on the int8 matrix pipe: auto (default) = 16-bit "
+                        "fixed point per weight while the dynamic range of the trained weights allows it (largest / rms "
+                        "weight per unit: median <= 64, worst <= 512 - predictions within 1e-3 relative, measured 5e-5 on a "
+                        "converged fit, tests/test_gpu_trained_predict.py), else as exact; exact = 24-bit (as accurate as "
+                        "fp32 accumulation; falls back to exactly-split bf16 when a unit's range exceeds 1024); fast = "
+                        "16-bit unconditionally")
+    p.add_argument("--predict_packed", default=True, action="store_true",
+                   help="(default) keep a 2-bit packed copy of every genotype matrix that is predicted from over 3072 "
+                        "rows or more (values 0..3 only): such predictions read a quarter of the genotype bytes, with "
+                        "identical results; one extra pass over the matrix, once")
+    p.add_argument("--no_predict_packed", dest="predict_packed", action="store_false",
+                   help="never keep the packed copy (saves a quarter of the matrix in device memory)")
     p.add_argument("--predict_pieces", default=None, type=int,
                    help="force the bf16 matrix pipe with this many pieces per first-layer weight instead: 3 = "
                         "fp32-exact products, 1 or 2 = faster, approximate (default: bf16 x 3 only where the int8 "
@@ -251,8 +259,7 @@ class Model:
             net.X, start = gen.X, gen.start
         else:
             net.X, start = upload_genotypes(np.asarray(gen), self.device), 0
-        if getattr(args, "predict_packed", False) and n >= 3072:
-            net.pack_genotypes()                      # cached on the matrix: a later predict from the same rows finds it
+        net.auto_pack = bool(getattr(args, "predict_packed", True))   # the packed copy is cached on the matrix itself
         net.cnet()
         rows = torch.arange(start, start + n, dtype=torch.int32, device=self.device)
         yhat = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
@@ -271,7 +278,7 @@ def predict_settings(a):
     forced = getattr(a, "predict_pieces", None)
     if forced is not None:
         return {"predict_pieces": int(forced), "predict_digits": -1}
-    return {"predict_pieces": 3, "predict_digits": 2 if getattr(a, "predict_mode", "exact") == "fast" else 3}
+    return {"predict_pieces": 3, "predict_digits": {"auto": 0, "exact": 3, "fast": 2}[getattr(a, "predict_mode", "auto")]}
 
 
 def load_network(traingen, dropout_prop, replicate=0, device="cuda:0"):
@@ -445,13 +452,34 @@ def _fit_unit(unit, device="cuda:0"):
     args = unit["args"]
     t_unit = time.time()
     phases = {}
-    if "window" in unit:
+    if "window" in unit and "gt_pin" not in unit:
         _load_window(unit)          # a no-op when the worker's loader thread has already done it (host_prepare)
     phases["load"] = time.time() - t_unit
-    tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
-    ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
-    key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
-    X = _BASE_CACHE.get(key) if key else None
+    X = None
+    if "gt_pin" in unit:
+        # the window's raw calls are in pinned memory: upload them as they are, filter + split + transpose on the device
+        import torch
+        from .net import filter_snps_device
+        shape = unit["gt_shape"]
+        nbytes = int(np.prod(shape, dtype=np.int64))
+        pin = unit.pop("gt_pin")
+        gt_dev = pin[:nbytes].to(device, non_blocking=True).view(torch.int8).view(*shape)
+        train, test, pred = unit["train"], unit["test"], unit["pred"]
+        order = np.concatenate([np.asarray(train), np.asarray(test), np.asarray(pred)]).astype(np.int32)
+        X, K = filter_snps_device(gt_dev, order, args.min_mac)
+        torch.cuda.current_stream().synchronize()
+        _pin_give(pin)
+        del gt_dev
+        if K < 1:
+            raise ValueError(f"{unit['name']}: no SNP passes the filters (biallelic, allele-1 count >= {args.min_mac})")
+        ntr, nva, npr = len(train), len(test), len(pred)
+        unit.update(trainlocs=unit["locs"][train], testlocs=unit["locs"][test])
+        key = None
+    else:
+        tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
+        ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
+        key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
+        X = _BASE_CACHE.get(key) if key else None
     if X is None:
         X = upload_genotypes(np.concatenate([np.asarray(tg), np.asarray(vg), np.asarray(pg).reshape(npr, K)], axis=0),
                              device)
@@ -484,11 +512,51 @@ def _fit_unit(unit, device="cuda:0"):
             "phases": phases, "epochs": len(history.history.get("loss", []))}
 
 
+_PIN_POOL = []          # per worker process: pinned staging buffers for window slices (torch uint8 tensors), reused
+_PIN_LOCK = __import__("threading").Lock()
+
+
+def _pin_take(nbytes):
+    import torch
+    with _PIN_LOCK:
+        for i, t in enumerate(_PIN_POOL):
+            if t.numel() >= nbytes:
+                return _PIN_POOL.pop(i)
+        _PIN_POOL.clear()                               # too small for this window: let them go, allocate with head room
+    return torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8).pin_memory()
+
+
+def _pin_give(t):
+    with _PIN_LOCK:
+        if len(_PIN_POOL) < 3:
+            _PIN_POOL.append(t)
+
+
+def _read_window(unit):
+    """Loader-thread half of a window on a GPU worker: ONLY the zarr slice gt[a:b] (locator.py:539), decoded straight into
+    pinned host memory.  Filters (locator.py:265-273) and the split's transposes (:295-308) then run on the device
+    (net.filter_snps_device in _fit_unit): the host phase of a 150,000-variant window drops from 0.68 s (NumPy allele counts +
+    boolean indexing + three transposed copies of a 230 MB slice) to the read itself."""
+    a, b = unit["window"]
+    gt = G.open_group(unit["zarr"], mode="r")["calldata/GT"]
+    shape = (max(min(b, gt.shape[0]) - a, 0),) + tuple(gt.shape[1:])
+    nbytes = int(np.prod(shape, dtype=np.int64))
+    pin = _pin_take(nbytes)
+    view = pin.numpy()[:nbytes].view(np.int8).reshape(shape)
+    gt.read_into(view, a, a + shape[0])
+    unit["gt_pin"], unit["gt_shape"] = pin, shape
+    return unit
+
+
 def _load_window_on_loader_thread(unit, a):
-    """ReplicatePool host_prepare hook: the zarr slice + filters of a window, run by the worker's loader thread while the
-    previous window is still fitting (they used to sit on every fit's critical path, locator.py:539-545)."""
+    """ReplicatePool host_prepare hook, run by the worker's loader thread while the previous window is still fitting
+    (slice + filters used to sit on every fit's critical path, locator.py:539-545): on a GPU worker the zarr slice only
+    (_read_window; the filters run on the device), otherwise - scheduler tests without a GPU - the host slice + filters."""
+    import torch
     u = dict(unit)
     u["args"] = a
+    if torch.cuda.is_available() and not getattr(a, "host_filter", False):
+        return _read_window(u)
     return _load_window(u)
 
 

@@ -22,6 +22,7 @@ LOC_BATCH_SLOT = 128     # rows per activation slot of the training scratch when
 LOC_MAX_FWD_GRID = 512
 LOC_GEMM_MIN_ROWS = {3: 1152, 2: 768, 1: 640}  # include/locator_hip.h, by bf16 pieces
 LOC_GEMM_I8_MIN_ROWS = 512                     # include/locator_hip.h: int8 image + GEMM
+LOC_GEMM_I8_PACKED_MIN_ROWS = 3072             # include/locator_hip.h: rows per chunk from which 2-bit packed genotypes pay
 
 
 def _ptr(t):
@@ -54,8 +55,11 @@ class LocatorNet:
 
     def __init__(self, X, Y, K, width=256, nlayers=10, dropout_prop=0.25, seed=0, replicate=0, device="cuda:0",
                  predict_pieces=3, predict_digits=3, tuning=None):
-        """predict_digits: int8 digit planes per weight in the many-row inference forward (3 = 24-bit fixed point against
-        each unit's largest weight, exact to fp32 accumulation; 2 = 16-bit, faster; -1 = never use the int8 pipe).
+        """predict_digits: int8 digit planes per weight in the many-row inference forward: 0 = AUTO (the default of the
+        command line): two planes (16-bit fixed point against each unit's largest weight) while the dynamic-range guard
+        of the weights allows it (include/locator_hip.h, LOC_GUARD_*: measured 5e-5 relative on the predictions of the
+        converged metric fit), else three, else the exact bf16 pieces; 3 = three planes (24 bits: no worse than an fp32
+        accumulation) under the same guard's exact limit; 2 = two planes unconditionally; -1 = never use the int8 pipe.
         predict_pieces: bf16 pieces per weight where the int8 GEMM does not apply - few rows, genotypes above 127 -
         (3 = exact fp32 products; 1 or 2 trade accuracy for speed, -1 keeps every row block on the 32-row fp32-MFMA
         kernel).  tuning: dict of loc_tuning fields (include/locator_hip.h) - speed hints and measurement switches,
@@ -97,6 +101,8 @@ class LocatorNet:
         self.tuning = _lib.Tuning(**{k: int(v) for k, v in (tuning or {}).items()})
         self.l1_image = None               # image of s_k*W1 for many-row predicts (allocated on first use)
         self._image_mode = 0               # loc_predict_image_mode() of the image l1_image holds for the current parameters
+        self._guard = None                 # (median R, max R, digits allowed, digits allowed in exact mode) of the current parameters
+        self.auto_pack = True              # many-row predicts keep a 2-bit packed copy of a matrix whose values are <= 3
         self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
         self._net = None
         self.init_weights()
@@ -110,6 +116,7 @@ class LocatorNet:
     def params_changed(self):
         """Weights, gamma/beta or BatchNorm moving statistics are about to change: a kept many-row weight image is stale."""
         self._image_mode = 0
+        self._guard = None
 
     def set_batch(self, batch_size):
         """Rows per training step (--batch_size).  Up to 32 rows use the 32-row kernels; 33..128 rows run two to
@@ -149,7 +156,7 @@ class LocatorNet:
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         n.slot_rows = self.slot_rows
         n.predict_pieces = self.predict_pieces
-        n.predict_digits = self.predict_digits
+        n.predict_digits = self.predict_digits if self.predict_digits != 0 else 3
         n.x_max = int(getattr(self.X, "loc_x_max", 0))      # set by genotype_max() on the tensor object itself
         if self.l1_image is not None:
             n.l1_image, n.l1_image_bytes = self.l1_image.data_ptr(), self.l1_image.numel()
@@ -318,22 +325,45 @@ class LocatorNet:
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
         lib, d = self.lib, self.d
-        use_i8 = (self.predict_pieces > 0 and self.predict_digits > 0 and n >= LOC_GEMM_I8_MIN_ROWS
-                  and lib.loc_l1_gemm_i8_supported(d.Hp, self.predict_digits))
+        capturing = torch.cuda.is_current_stream_capturing()
+        digits = self.predict_digits if self.predict_digits != 0 else 3
+        use_i8 = (self.predict_pieces > 0 and digits > 0 and n >= LOC_GEMM_I8_MIN_ROWS
+                  and lib.loc_l1_gemm_i8_supported(d.Hp, digits))
         if use_i8 and self.genotype_max() > 127:
             use_i8 = False
+        guarded = use_i8 and self.predict_digits in (0, 3) and not capturing
         need = 0
         if use_i8:
-            need = lib.loc_l1_image_i8_bytes(C.byref(d), self.predict_digits)
+            need = lib.loc_l1_image_i8_bytes(C.byref(d), 3 if self.predict_digits == 0 else digits)
         elif (self.predict_pieces > 0 and n >= LOC_GEMM_MIN_ROWS.get(self.predict_pieces, 1 << 30)
               and lib.loc_l1_gemm_supported(d.Hp, self.predict_pieces)):
             need = lib.loc_l1_image_bytes(C.byref(d), self.predict_pieces)
+        if guarded:
+            need = max(need, lib.loc_l1_image_bytes(C.byref(d), 3))      # the guard may send the weights to bf16 x 3
         if need and (self.l1_image is None or self.l1_image.numel() < need):
             # many rows: W1 is converted once per call into this buffer (include/locator_hip.h, loc_net.l1_image)
             self.l1_image = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._image_mode = 0           # a fresh buffer holds nothing
+            self._guard = None
             self._net = None
         net = self._net or self.cnet()
+        net.l1_scan_ready = 0
+        if guarded:
+            # the dynamic-range guard decides the digit planes (LOC_GUARD_*): one pass over W1 that the image build would
+            # make anyway, four floats read back - the one synchronising step of a many-row predict, once per set of weights
+            fresh = self._guard is None
+            g = self.quant_guard()
+            allowed = int(g[2] if self.predict_digits == 0 else g[3])
+            net.predict_digits = allowed                   # 2, 3 or -1 (bf16 x 3 pieces)
+            if allowed < 0:
+                net.predict_pieces = 3
+            net.l1_scan_ready = 1 if (fresh and allowed > 0) else 0   # the header still holds this scan
+        if (use_i8 and net.predict_digits > 0 and self.auto_pack and n >= LOC_GEMM_I8_PACKED_MIN_ROWS and not capturing
+                and getattr(self.X, "loc_x2", None) is None and self.genotype_max() <= 3):
+            self.pack_genotypes()          # one pass, kept on the matrix: every later many-row predict reads a quarter of the bytes
+            keep = (net.predict_digits, net.predict_pieces, net.l1_scan_ready)
+            net = self.cnet()
+            net.predict_digits, net.predict_pieces, net.l1_scan_ready = keep
         # predict_locs predicts twice with the same weights (locator.py:414, :441): the second call finds the image
         mode = lib.loc_predict_image_mode(C.byref(net), int(n))
         net.l1_image_ready = mode if (mode and mode == self._image_mode
@@ -342,6 +372,29 @@ class LocatorNet:
                                         _ptr(dist), _stream()), "loc_predict")
         if mode:
             self._image_mode = mode
+        # per-call choices never outlive the call
+        net.predict_digits = self.predict_digits if self.predict_digits != 0 else 3
+        net.predict_pieces = self.predict_pieces
+        net.l1_scan_ready = 0
+
+    def quant_guard(self):
+        """(median R, largest R, digit planes allowed, digit planes allowed in exact mode) of the current parameters, R_h =
+        largest / rms scaled first-layer weight of unit h (loc_l1_quant_scan; include/locator_hip.h LOC_GUARD_*).  Synchronises
+        the current stream; cached until the parameters change."""
+        if self._guard is None:
+            lib, d = self.lib, self.d
+            need = lib.loc_l1_image_i8_bytes(C.byref(d), 2)
+            if self.l1_image is None or self.l1_image.numel() < need:
+                self.l1_image = torch.empty(max(need, lib.loc_l1_image_i8_bytes(C.byref(d), 3)), dtype=torch.uint8, device=self.device)
+                self._image_mode = 0
+                self._net = None
+            net = self._net or self.cnet()
+            _lib.check(lib.loc_predict_scan(C.byref(net), _stream()), "loc_predict_scan")
+            off = int(lib.loc_l1_image_i8_guard_offset())
+            g = self.l1_image[off:off + 16].view(torch.float32).cpu().numpy()
+            self._guard = tuple(float(v) for v in g)
+            self._image_mode = 0           # the scan borrowed the image's shift-term section
+        return self._guard
 
     def genotype_max(self):
         """Largest genotype value of the current X (one streaming pass, cached per matrix): decides whether the rows
@@ -397,3 +450,27 @@ def gather_columns(X, site_order, K):
     _lib.check(lib.loc_gather_columns(_ptr(X), X.stride(0), _ptr(so), int(K), _ptr(out), out.stride(0),
                                       X.shape[0], _stream()), "loc_gather_columns")
     return out
+
+
+def filter_snps_device(gt, sample_order, min_mac=2):
+    """filter_snps (locator.py:265-273, no --impute_missing / --max_SNPs) and the split's `ac[:, rows].T` (:295-308) on the
+    device.  gt: int8 device tensor [n_variants][n_samples][ploidy] (the window's zarr slice, uploaded as it is);
+    sample_order: the rows wanted, in output order (train | validation | prediction).  Returns (X uint8 [len(order)][Kp],
+    K).  One host synchronisation: the SNP count decides the allocation."""
+    lib = _lib.load()
+    assert gt.dtype == torch.int8 and gt.is_cuda and gt.is_contiguous() and gt.dim() == 3
+    V, N, P = (int(v) for v in gt.shape)
+    dev = gt.device
+    keep = torch.empty(V, dtype=torch.uint8, device=dev)
+    pos = torch.empty(V, dtype=torch.int32, device=dev)
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.loc_filter_snps_flags(_ptr(gt), V, N, P, int(min_mac), _ptr(keep), _ptr(pos), _ptr(nk), _stream()),
+               "loc_filter_snps_flags")
+    K = int(nk.item())
+    order = torch.as_tensor(np.asarray(sample_order, dtype=np.int32)).to(dev)
+    Kp = (max(K, 1) + 31) // 32 * 32
+    X = torch.zeros((len(order), Kp), dtype=torch.uint8, device=dev)
+    if K > 0:
+        _lib.check(lib.loc_filter_snps_rows(_ptr(gt), V, N, P, _ptr(keep), _ptr(pos), _ptr(order), len(order), _ptr(X),
+                                            X.stride(0), _stream()), "loc_filter_snps_rows")
+    return X, K

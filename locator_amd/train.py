@@ -76,7 +76,10 @@ class EpochRunner:
         self.steps = (self.n_train + self.batch - 1) // self.batch
         self.n_val = len(val_rows)
         self.val_rows = torch.as_tensor(np.asarray(val_rows, dtype=np.int32)).to(dev)
-        self.perm_host = torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory()
+        self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory()]
+        self.perm_host = self.perm_ring[0]
+        self.epochs_started = 0
+        self.cb = None                       # device-side callbacks (enable_device_callbacks)
         self.perm_dev = torch.zeros(self.steps * self.batch, dtype=torch.int32, device=dev)
         # keep flags per step: [rows][Hp], or [32][Kp] when the Dropout layer sits on the BatchNorm output (--nlayers 1)
         self.mask_stride = self.slot_rows * net.mask_width
@@ -93,6 +96,38 @@ class EpochRunner:
         self.step_sizes = np.array([min(self.batch, self.n_train - j * self.batch) for j in range(self.steps)])
         net.cnet()
         self.chain = net.chain_supported() if chain is None else (bool(chain) and net.chain_supported())
+
+    def enable_device_callbacks(self, patience, lr0, lr_patience, lr_factor, max_epochs, depth=2):
+        """ModelCheckpoint / EarlyStopping / ReduceLROnPlateau evaluated on the device at the end of every epoch
+        (loc_epoch_callbacks + loc_snapshot_if, part of the epoch's stream / captured graph), so epochs can be enqueued
+        `depth` ahead of the device.  Must be called before the first epoch."""
+        import ctypes as C
+        from . import _lib
+        assert self.epochs_started == 0 and self.graph is None
+        net, dev = self.net, self.net.device
+        st = _lib.CbState()
+        st.ck_best = st.es_best = st.rl_best = float("inf")
+        st.lr = float(np.float32(lr0))
+        st.lr_factor = float(lr_factor)
+        st.patience = int(patience)
+        st.lr_patience = int(patience / 6) if lr_patience is None else int(lr_patience)      # locator.py:354
+        st.stop_epoch = st.best_epoch = -1
+        raw = np.frombuffer(bytes(st), dtype=np.uint8).copy()
+        cap = int(max_epochs)
+        self.cb = {"state": torch.from_numpy(raw).to(dev), "hist": torch.zeros((cap, 4), dtype=torch.float64, device=dev),
+                   "hist_host": torch.zeros((cap, 4), dtype=torch.float64).pin_memory(), "cap": cap, "depth": int(depth),
+                   "events": [torch.cuda.Event() for _ in range(int(depth) + 2)], "state_size": C.sizeof(_lib.CbState)}
+        if net.best is None:
+            net.best = torch.empty_like(net.params)
+        net.lr_t.fill_(st.lr)
+        self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory() for _ in range(int(depth) + 2)]
+        self.perm_host = self.perm_ring[0]
+
+    def read_cb_state(self):
+        """The device's callback state (synchronises): a _lib.CbState."""
+        from . import _lib
+        raw = self.cb["state"].cpu().numpy().tobytes()
+        return _lib.CbState.from_buffer_copy(raw)
 
     def enqueue(self, ev=None):
         net = self.net
@@ -115,6 +150,15 @@ class EpochRunner:
                            bn_ready=True, bn_next=nxt)
         if self.n_val:
             net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
+        if self.cb is not None:
+            from . import _lib
+            from .net import _ptr, _stream
+            cb = self.cb
+            _lib.check(net.lib.loc_epoch_callbacks(_ptr(self.stats), self.steps, self.batch, int(self.step_sizes[-1]), self.n_val,
+                                                   _ptr(cb["state"]), _ptr(net.lr_t), _ptr(cb["hist"]), cb["cap"], _stream()),
+                       "loc_epoch_callbacks")
+            _lib.check(net.lib.loc_snapshot_if(_ptr(cb["state"]), _ptr(net.params), _ptr(net.best), net.params.numel(),
+                                               _stream()), "loc_snapshot_if")
         net.t_base_t.add_(self.steps)
 
     def start_epoch(self, perm, ev=None):
@@ -124,13 +168,17 @@ class EpochRunner:
         net = self.net
         net.params_changed()                 # a graph replay trains without passing through net.train_step
         rows = self.train_rows[np.asarray(perm)]
+        # pinned staging buffers rotate: with epochs enqueued ahead of the device the copy of epoch e is still pending
+        # when the host prepares epoch e + 1 (the ring is depth + 2 long and FitLoop waits for epoch e - depth first)
+        self.perm_host = self.perm_ring[self.epochs_started % len(self.perm_ring)]
         self.perm_host[:self.n_train] = torch.from_numpy(rows)
         self.perm_host[self.n_train:] = 0
         self.perm_dev.copy_(self.perm_host, non_blocking=True)
         if self.masks is not None:
-            net.fill_dropout_masks(self.masks, self.masks.numel(), self.epochs_run * self.masks.numel())
+            net.fill_dropout_masks(self.masks, self.masks.numel(), self.epochs_started * self.masks.numel())
+        self.epochs_started += 1
         if self.use_graph and ev is None:
-            if self.graph is None and self.epochs_run >= 1:      # epoch 0 ran eagerly = warm-up
+            if self.graph is None and self.epochs_started >= 2:   # epoch 0 ran eagerly = warm-up
                 g = torch.cuda.CUDAGraph()
                 cur = torch.cuda.current_stream()
                 # capture is not allowed on the default stream: torch then captures on a side stream of its own
@@ -161,41 +209,113 @@ class EpochRunner:
         return self.finish_epoch()
 
 
+class FitLoop:
+    """model.fit's epoch loop with the callbacks on the device (locator.py:365-376): `submit()` enqueues the next epoch
+    (permutation upload, dropout masks, the epoch's kernels or its captured graph, the callback kernel, the predicated
+    checkpoint copy, and a copy of the epoch's history row to pinned host memory) and returns at once; `collect(lag)`
+    waits for the epochs at least `lag` behind the last one submitted and folds their rows into the History.  The host
+    therefore runs up to `depth` epochs ahead of the device; what it reads back (loss, val_loss, the LR the epoch trained
+    with, what the callbacks did) was decided on the device, so a synchronous run (depth 0) and a pipelined one produce
+    the same history, the same best weights and the same predictions bit for bit - the only difference is up to
+    `depth` epochs enqueued behind the stop epoch, which change nothing that is kept (frozen state, include/locator_hip.h)."""
+
+    def __init__(self, net, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
+                 lr_factor=0.5, perm_fn=None, use_graph=True, chain=None, depth=2, verbose=0, log=print):
+        if len(val_rows) == 0:
+            raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
+        self.net = net
+        self.runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain)
+        self.max_epochs, self.depth = int(max_epochs), max(0, int(depth))
+        self.runner.enable_device_callbacks(patience, 1e-3, lr_patience, lr_factor, self.max_epochs, self.depth)
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))
+        self.perm_fn = perm_fn if perm_fn is not None else (lambda epoch: rng.permutation(self.runner.n_train))
+        self.hist = History()
+        self.submitted = 0          # epochs enqueued
+        self.collected = 0          # epochs whose history row has been read
+        self.stop_epoch = None      # index of the epoch at which early stopping fired, once seen
+        self.verbose, self.log = verbose, log
+        self._t_last = time.perf_counter()
+
+    @property
+    def done(self):
+        return self.stop_epoch is not None or self.collected >= self.max_epochs
+
+    def submit(self, ev=None):
+        """Enqueue the next epoch on the current stream (no-op once max_epochs are enqueued or the stop was seen)."""
+        if self.stop_epoch is not None or self.submitted >= self.max_epochs:
+            return False
+        e, cb = self.submitted, self.runner.cb
+        self.runner.start_epoch(self.perm_fn(e), ev)
+        cb["hist_host"][e].copy_(cb["hist"][e], non_blocking=True)
+        cb["events"][e % len(cb["events"])].record(torch.cuda.current_stream())
+        self.submitted += 1
+        return True
+
+    def collect(self, lag=None):
+        """Fold in the history rows of every epoch at least `lag` behind the newest submitted one (default: depth; 0 =
+        wait for everything submitted).  Returns True once the fit is over (early stopping seen or max_epochs collected)."""
+        lag = self.depth if lag is None else lag
+        cb = self.runner.cb
+        while self.stop_epoch is None and self.collected < self.submitted - lag:
+            e = self.collected
+            cb["events"][e % len(cb["events"])].synchronize()
+            loss, val, lr_logged, flags = (float(v) for v in cb["hist_host"][e])
+            flags = int(flags)
+            h = self.hist.history
+            h["loss"].append(loss)
+            h["val_loss"].append(val)
+            h["learning_rate"].append(lr_logged)
+            now = time.perf_counter()
+            self.hist.epoch_seconds.append(now - self._t_last)
+            self._t_last = now
+            self.collected += 1
+            self.runner.epochs_run = self.collected
+            if self.verbose:
+                if flags & 4:
+                    self.log(f"\nEpoch {e + 1}: ReduceLROnPlateau reducing learning rate to "
+                             f"{float(np.float32(lr_logged) * np.float32(self.runner_lr_factor))}.")
+                self.log(f"Epoch {e + 1}/{self.max_epochs} - loss: {loss:.4f} - val_loss: {val:.4f} - "
+                         f"learning_rate: {lr_logged:.4e}")
+            if flags & 2:
+                self.stop_epoch = e
+        return self.done
+
+    @property
+    def runner_lr_factor(self):
+        return float(self.runner.read_cb_state().lr_factor) if self.verbose else 0.5
+
+    def finish(self):
+        """After the last collect: wait for the device, check that a checkpoint exists, reload the best weights
+        (locator.py:379-388).  Returns the History."""
+        self.collect(0)
+        self.runner._stream = torch.cuda.current_stream()
+        self.runner._stream.synchronize()
+        st = self.runner.read_cb_state()
+        h = self.hist.history
+        if st.best_epoch < 0:
+            # val_loss was never finite (diverged fit): the reference dies here too, load_weights finds no checkpoint file
+            raise RuntimeError(f"training produced no checkpoint: val_loss was never finite in {len(h['loss'])} "
+                               f"epochs (last loss {h['loss'][-1]}, last val_loss {h['val_loss'][-1]})")
+        self.hist.best_epoch = int(st.best_epoch)
+        self.net.restore_best()
+        return self.hist
+
+    def run(self):
+        while not self.done:
+            if not self.submit():
+                self.collect(0)
+                break
+            self.collect()
+        return self.finish()
+
+
 def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
-        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print, chain=None):
+        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print, chain=None, pipelined=True, depth=2):
     """train_network (locator.py:365-394): fit with checkpoint / early-stop / LR-plateau callbacks, then
-    reload the best weights.  Returns a History.  lr_patience None = int(patience / 6) (locator.py:354)."""
-    if len(val_rows) == 0:
-        raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
-    runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain)
-    cb = Callbacks(patience, 1e-3, lr_patience, lr_factor)
-    hist = History()
-    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))
-    if perm_fn is None:
-        perm_fn = lambda epoch: rng.permutation(runner.n_train)
-    net.lr_t.fill_(cb.lr)
-    for epoch in range(max_epochs):
-        t0 = time.perf_counter()
-        loss, val = runner.run_epoch(perm_fn(epoch))
-        save, stop, lr_logged = cb.on_epoch_end(epoch, val)
-        hist.history["loss"].append(loss)
-        hist.history["val_loss"].append(val)
-        hist.history["learning_rate"].append(lr_logged)
-        if save:
-            net.snapshot()
-        if cb.lr != lr_logged:
-            net.lr_t.fill_(cb.lr)
-            if verbose:
-                log(f"\nEpoch {epoch + 1}: ReduceLROnPlateau reducing learning rate to {cb.lr}.")
-        hist.epoch_seconds.append(time.perf_counter() - t0)
-        if verbose:
-            log(f"Epoch {epoch + 1}/{max_epochs} - loss: {loss:.4f} - val_loss: {val:.4f} - "
-                f"learning_rate: {lr_logged:.4e}")
-        if stop:
-            break
-    if net.best is None:
-        # val_loss was never finite (diverged fit): the reference dies here too, load_weights finds no checkpoint file
-        raise RuntimeError(f"training produced no checkpoint: val_loss was never finite in {len(hist.history['loss'])} "
-                           f"epochs (last loss {hist.history['loss'][-1]}, last val_loss {hist.history['val_loss'][-1]})")
-    net.restore_best()
-    return hist
+    reload the best weights.  Returns a History.  lr_patience None = int(patience / 6) (locator.py:354).
+    pipelined: the host enqueues epochs `depth` ahead of the device (False = wait for every epoch before enqueueing the
+    next; same kernels, same decisions - they are taken on the device either way - same results bit for bit)."""
+    loop = FitLoop(net, train_rows, val_rows, batch_size=batch_size, max_epochs=max_epochs, patience=patience,
+                   lr_patience=lr_patience, lr_factor=lr_factor, perm_fn=perm_fn, use_graph=use_graph, chain=chain,
+                   depth=depth if pipelined else 0, verbose=verbose, log=log)
+    return loop.run()

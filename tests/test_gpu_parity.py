@@ -297,3 +297,86 @@ def test_bad_arguments_fail_loudly():
         net.train_step(_rows(np.arange(4)), 0, 1, None, torch.zeros(1, device="cuda"))
     with pytest.raises(_lib.LocatorHipError):           # dropout > 0 without a mask
         net.train_step(_rows(np.arange(4)), 4, 1, None, torch.zeros(1, device="cuda"))
+
+
+def _callback_run(pipelined, depth=2, use_graph=True, max_epochs=60, patience=5):
+    from locator_amd.train import fit
+    x, y, p, rng = make_problem(140, 400, 64, 4, seed=4)
+    tr, va = np.arange(0, 110), np.arange(110, 140)
+    net = build_net(x, y, p, seed=2)
+    h = fit(net, tr, va, max_epochs=max_epochs, patience=patience, lr_patience=2, pipelined=pipelined, depth=depth,
+            use_graph=use_graph)
+    yhat = torch.zeros((140, 2), device="cuda")
+    net.predict_rows(torch.arange(140, dtype=torch.int32, device="cuda"), 140, yhat)
+    _sync()
+    return h, net.params.cpu().numpy().copy(), net.lr_t.item(), yhat.cpu().numpy().copy()
+
+
+def test_pipelined_fit_is_bit_identical_to_the_synchronous_loop():
+    """the callbacks run on the device (loc_epoch_callbacks + loc_snapshot_if in the epoch's graph)
+    and the host enqueues epochs ahead of it.  History, restored best weights, final learning rate and predictions of
+    fit(pipelined=True) at two depths equal fit(pipelined=False) bit for bit, with and without graph capture; the epochs
+    enqueued behind the stop epoch leave no trace (the device state is frozen once early stopping fires)."""
+    ref = _callback_run(False)
+    ne = len(ref[0].history["loss"])
+    assert 7 <= ne < 60, ne                                   # early stopping did fire, and not at once
+    assert len(set(ref[0].history["learning_rate"])) >= 2     # ... after at least one LR reduction
+    for kw in ({"depth": 2}, {"depth": 4}, {"depth": 1, "use_graph": False}):
+        got = _callback_run(True, **kw)
+        assert got[0].history == ref[0].history, kw
+        assert got[0].best_epoch == ref[0].best_epoch
+        assert np.array_equal(got[1], ref[1]) and got[2] == ref[2] and np.array_equal(got[3], ref[3]), kw
+
+
+def test_device_callbacks_follow_the_keras_state_machines():
+    """The device's decisions (checkpoint / stop / LR) replayed through the host restatement of the three Keras callbacks
+    (train.Callbacks = SURVEY.md A.5, itself checked against oracle.Callbacks in the CPU suite) on the device's own
+    val_loss sequence: same save epochs, same stop epoch, same learning-rate column."""
+    from locator_amd.train import Callbacks
+    h, _, lr_end, _ = _callback_run(True, max_epochs=80, patience=6)
+    hh = h.history
+    cb = Callbacks(6, 1e-3, 2, 0.5)
+    saves, stop_at, lrs = [], None, []
+    for e, v in enumerate(hh["val_loss"]):
+        save, stop, lr_logged = cb.on_epoch_end(e, v)
+        lrs.append(lr_logged)
+        if save:
+            saves.append(e)
+        if stop:
+            stop_at = e
+            break
+    assert lrs == hh["learning_rate"]
+    assert (stop_at is None and len(hh["loss"]) == 80) or stop_at == len(hh["loss"]) - 1
+    assert h.best_epoch == saves[-1] == int(np.argmin(hh["val_loss"]))
+    assert lr_end == float(np.float32(cb.lr))
+
+
+def test_pipelined_fit_matches_oracle_fit_with_callbacks():
+    """Callback-driven fit (early stopping + LR plateau live) against oracle.fit on the same permutations and the device's
+    dropout masks: per-epoch loss / val_loss 5e-4, the same number of epochs and LR column, predictions 1e-3 relative."""
+    from locator_amd.train import FitLoop
+    K, width, nlayers = 600, 64, 4
+    x, y, p, rng = make_problem(130, K, width, nlayers, seed=21)
+    tr, va, pr_rows = np.arange(0, 100), np.arange(100, 120), np.arange(120, 130)
+    net = build_net(x, y, p, drop_p=0.25, seed=11)
+    perms = [np.random.default_rng(100 + e).permutation(100) for e in range(12)]
+    loop = FitLoop(net, tr, va, batch_size=32, max_epochs=12, patience=12, perm_fn=lambda e: perms[e], depth=0)   # LR patience int(12 / 6) = 2
+    masks = []
+    while not loop.done:
+        loop.submit()
+        loop.collect(0)
+        masks.append(loop.runner.masks.cpu().numpy().reshape(loop.runner.steps, 32, net.d.Hp).copy())
+    hist = loop.finish().history
+    pref = O.copy_params(p)
+    href, best = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=32, max_epochs=12, patience=12, drop_p=0.25,
+                       perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s, :nb, :width])
+    assert len(hist["loss"]) == len(href["loss"])
+    assert maxerr(hist["loss"], href["loss"]) < 5e-4 and maxerr(hist["val_loss"], href["val_loss"]) < 5e-4
+    lr_key = "learning_rate" if "learning_rate" in href else "lr"
+    assert [float(np.float32(v)) for v in href[lr_key]] == hist["learning_rate"]
+    yhat = torch.zeros((10, 2), device="cuda")
+    net.predict_rows(torch.from_numpy(pr_rows.astype(np.int32)).cuda(), 10, yhat)
+    _sync()
+    ref = O.predict(best, x[pr_rows])                 # fit reloads the best-val_loss weights (locator.py:379-388)
+    rel = np.abs(yhat.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1.0)
+    assert rel.max() < 1e-3, rel.max()

@@ -655,3 +655,24 @@ def test_pool_reports_a_loader_thread_failure_instead_of_hanging(monkeypatch):
     assert time.time() - t0 < 120
     assert len(res) == 4 and all(r is not None and "error" in r for r in res), res
     assert any("loader thread failed" in str(l) for l in logs), logs
+
+
+def test_zarr_read_into_equals_getitem(tmp_path):
+    """ZarrArray.read_into (the --windows loader reads a slice straight into pinned memory): uncompressed chunks through
+    file offsets, compressed chunks through the threaded decode, partial first / last chunks, a missing chunk."""
+    rng = np.random.default_rng(3)
+    gt = rng.integers(-1, 3, (1000, 17, 2)).astype(np.int8)
+    for comp in (None, "blosc", "zlib"):
+        p = str(tmp_path / ("gt_" + str(comp)))
+        G.write_zarr_array(p, gt, (128, 17, 2), compressor=comp)
+        za = G.ZarrArray(p)
+        for a, b in ((0, 1000), (5, 130), (128, 256), (300, 301), (900, 1000), (0, 0)):
+            out = np.full((b - a, 17, 2), 99, np.int8)
+            za.read_into(out, a, b, threads=3)
+            assert np.array_equal(out, gt[a:b]) and np.array_equal(za[a:b], gt[a:b])
+        os.remove(os.path.join(p, "2.0.0"))
+        out = np.full((384, 17, 2), 99, np.int8)
+        za.read_into(out, 128, 512)
+        assert np.array_equal(out[:128], gt[128:256]) and not out[128:256].any() and np.array_equal(out[256:], gt[384:512])
+    with pytest.raises(ValueError):
+        za.read_into(np.zeros((3, 17, 2), np.int16), 0, 3)
