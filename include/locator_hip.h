@@ -100,6 +100,9 @@ typedef struct loc_tuning {
     int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
+    int gemm_reduce;      /* many-row predicts on the int8 pipe: 0 = default: the SNP-group sum + shift + b1 + ELU of the layer-1
+                             GEMM happens in the input stage of the hidden-stack launch (no reduction launch, no a1 round
+                             trip); 1 = the separate l1_gemm_reduce_kernel launch (same bits; measurement switch)               */
     int chain_tail;       /* chained steps (loc_train_step_chain): 0 = default: the step's hidden-layer / head Adam tail runs
                              as trailing workgroups of the chained layer-1 launch (they fill the compute units that finish
                              their k-tiles an iteration early); -1 = its own launch after it (measurement switch)          */
@@ -301,6 +304,15 @@ int loc_l1_image_i8_build_scanned(const loc_dims* d, const float* scale_shift, c
 int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
                            const void* image, int digits, int x_max, const float* b1, float* partial,
                            int64_t partial_floats, float* a1, int target_blocks, const loc_tuning* tune, void* stream);
+/* loc_l1_forward_gemm_i8 (packed != 0: loc_l1_forward_gemm_i8_packed, X / x_pitch then are the packed matrix's) WITHOUT its
+ * reduction launch: the SNP-group partial sums stay in `partial` as [*h_groups][ceil(n/128)*128][256] floats and *cvec8
+ * points at the image's 8 x 256 shift-term slices; loc_stack_forward_eval_partial adds them up (+ b1, ELU) in the input
+ * stage of the hidden-stack launch - the same association as the reduction kernel, so the same bits.  h_groups and cvec8
+ * are HOST pointers written before the call returns. */
+int loc_l1_forward_gemm_i8_partial(const uint8_t* X, int64_t x_pitch, int packed, const int32_t* rows, int n,
+                                   const loc_dims* d, const void* image, int digits, int x_max, float* partial,
+                                   int64_t partial_floats, int target_blocks, const loc_tuning* tune, int* h_groups,
+                                   const float** cvec8, void* stream);
 /* Fused: dW1 = xhat^T dZ1, dxhat = dZ1 W1^T -> dgamma/dbeta, Adam on W1/gamma/beta/b1.
  * dW1 and dxhat are never written to memory.  gb_scratch: (Kp/32)*128 floats (per-wave partial
  * sums for dgamma/dbeta, combined in a fixed order by a trailing per-SNP kernel).  If bn_next_stats
@@ -387,6 +399,12 @@ int loc_stack_forward_backward(const float* a1_in, const float* Wh, const float*
 int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
                            const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
                            const float* Y, float* yhat, float* dist, void* stream);
+/* loc_stack_forward_eval whose layer-1 activations are still the many-row GEMM's group partial sums
+ * (loc_l1_forward_gemm_i8_partial): a1[m][h] = ELU(sum_g partial[g * group_stride + m * Hp + h] + sum_s cvec8[s * Hp + h] + b1[h]). */
+int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t group_stride, const float* cvec8,
+                                   const float* b1, const float* Wh, const float* bh, const float* wa, const float* ba,
+                                   const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
+                                   const float* Y, float* yhat, float* dist, void* stream);
 /* ONE launch: dW, db + Adam for every hidden layer (one workgroup per 32x32 tile, W^T refreshed), head
  * gradients + Adam, and the batch-mean loss (to *loss_out). */
 int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts, const float* adrop,

@@ -40,7 +40,7 @@ class Layout(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("stack_helpers", C.c_int), ("stack_xcd_stride", C.c_int), ("l1b_nt_mask", C.c_int),
-                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("chain_tail", C.c_int)]
+                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("gemm_reduce", C.c_int), ("chain_tail", C.c_int)]
 
 
 class Net(C.Structure):
@@ -97,6 +97,10 @@ SIGNATURES = {
     "loc_l1_image_i8_guard_offset": (C.c_int64, []),
     "loc_l1_image_i8_build_scanned": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_predict_scan": (C.c_int, [C.POINTER(Net), vp]),
+    "loc_l1_forward_gemm_i8_partial": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp,
+                                                 C.c_int64, C.c_int, C.POINTER(Tuning), C.POINTER(C.c_int), C.POINTER(vp), vp]),
+    "loc_stack_forward_eval_partial": (C.c_int, [vp, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                                                 C.c_int, vp, vp, vp, vp, vp]),
     "loc_l1_forward_gemm_i8": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp, vp,
                                          C.c_int64, vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_genotype_max": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp]),

@@ -364,6 +364,21 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         }
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
+            if (i8 && L >= 2 && net->tune.gemm_reduce == 0) {
+                // int8 GEMM -> hidden stack with the group reduction in the stack kernel's input stage
+                const bool pk = net->X2 && net->x_max <= 3 && nc >= LOC_GEMM_I8_PACKED_MIN_ROWS;
+                int groups = 0;
+                const float* cvec8 = nullptr;
+                TRY(loc_l1_forward_gemm_i8_partial(pk ? net->X2 : net->X, pk ? net->x2_pitch : net->x_pitch, pk ? 1 : 0,
+                                                   rows + c0, nc, d, net->l1_image, digits, net->x_max, w.partial,
+                                                   w.partial_floats, 0, &net->tune, &groups, &cvec8, stream));
+                const int64_t mp = (int64_t)((nc + LOC_ROWS_TILE - 1) / LOC_ROWS_TILE) * LOC_ROWS_TILE;
+                TRY(loc_stack_forward_eval_partial(w.partial, groups, mp * Hp, cvec8, P + lay.b1, P + lay.wh, P + lay.bh,
+                                                   P + lay.wa, P + lay.ba, P + lay.wb, P + lay.bb, Hp, L, nc,
+                                                   with_targets ? rows + c0 : nullptr, with_targets ? net->Y : nullptr,
+                                                   yhat + 2 * (int64_t)c0, with_targets ? dist + c0 : nullptr, stream));
+                continue;
+            }
             if (i8 && net->X2 && net->x_max <= 3 && nc >= LOC_GEMM_I8_PACKED_MIN_ROWS)
                 TRY(loc_l1_forward_gemm_i8_packed(net->X2, net->x2_pitch, rows + c0, nc, d, net->l1_image, digits,
                                                   P + lay.b1, w.partial, w.partial_floats, w.a1_rows, 0, &net->tune, stream));

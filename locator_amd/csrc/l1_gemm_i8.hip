@@ -660,9 +660,11 @@ extern "C" int loc_l1_image_i8_build_scanned(const loc_dims* d, const float* sca
     return g8_image_build(d, scale_shift, w1s, digits, image, true, stream);
 }
 
+// a1 == nullptr: the SNP-group partial sums stay in `partial` ([groups][ceil(n/128)*128][256] floats; *groups_out groups)
+// for a consumer that adds them up itself (loc_stack_forward_eval_partial)
 static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d, const void* image,
                       int digits, int x_max, const float* b1, float* partial, int64_t partial_floats, float* a1,
-                      int target_blocks, const loc_tuning* tune, bool packed, void* stream) {
+                      int target_blocks, const loc_tuning* tune, bool packed, void* stream, int* groups_out = nullptr) {
     if (n < 1) { loc_set_error("loc_l1_forward_gemm_i8: n=%d", n); return -1; }
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) {
         loc_set_error("loc_l1_forward_gemm_i8: width %d / %d digits unsupported", d->Hp, digits);
@@ -725,7 +727,19 @@ static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, in
     }
 #undef G8_LAUNCH
     LOC_CHECK_LAUNCH();
+    if (groups_out) *groups_out = G;
+    if (!a1) return 0;
     return gm_launch_reduce(partial, G, (int64_t)Mp * G8_HP, cvec, b1, a1, stream);
+}
+
+extern "C" int loc_l1_forward_gemm_i8_partial(const uint8_t* X, int64_t x_pitch, int packed, const int32_t* rows, int n,
+                                              const loc_dims* d, const void* image, int digits, int x_max, float* partial,
+                                              int64_t partial_floats, int target_blocks, const loc_tuning* tune,
+                                              int* h_groups, const float** cvec8, void* stream) {
+    if (!h_groups || !cvec8) { loc_set_error("loc_l1_forward_gemm_i8_partial: h_groups / cvec8 must not be NULL"); return -1; }
+    *cvec8 = reinterpret_cast<const float*>(image);
+    return g8_forward(X, x_pitch, rows, n, d, image, digits, packed ? 3 : x_max, nullptr, partial, partial_floats, nullptr,
+                      target_blocks, tune, packed != 0, stream, h_groups);
 }
 
 extern "C" int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     const float* __restrict__ wb, const float* __restrict__ bb, const uint8_t* __restrict__ mask, float keep_scale,
     int L, int n_pre, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ acts, float* __restrict__ adrop, float* __restrict__ dz, float* __restrict__ head_out,
-    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work, int slot_rows) {
+    float* __restrict__ yhat, float* __restrict__ dist, int xcd_stride, int n_work, int slot_rows,
+    const float* __restrict__ rd_partial, int rd_G, int64_t rd_MH, const float* __restrict__ rd_cvec8,
+    const float* __restrict__ rd_b1) {
     constexpr int Hp = NHT * 32;
     constexpr int C4 = Hp / 4;               // float4 columns per weight row
     constexpr int KG = SF_THREADS / C4;      // k-groups
@@ -75,7 +77,35 @@ __global__ __launch_bounds__(SF_THREADS) void stack_fused_kernel(
     const int64_t blk = (int64_t)slot_rows * Hp, HH = (int64_t)Hp * Hp;      // slot = activations of one layer
 
     // rows of this block: input of layer 2
-    for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = a1_in[(int64_t)(r0 + i / Hp) * Hp + i % Hp];
+    if (!TRAIN && rd_partial != nullptr) {
+        // the many-row layer-1 GEMM left its SNP-group partial sums: the group sum + shift term + b1 + ELU that
+        // l1_gemm_reduce_kernel would do in a launch of its own (33 MB read back by one kernel at 1000 and at 4096 rows)
+        // happens here, spread over every row block of the stack launch.  Same association as that kernel - four
+        // quarters of the groups, ((q0 + q1) + q2) + q3, then + (shift + b1) - so the activations are the same bits.
+        const int gq = (rd_G + 3) / 4;
+        for (int i = t; i < R * Hp; i += SF_THREADS) {
+            const int r = i / Hp, n = i % Hp;
+            float v = 0.f;
+            if (r0 + r < n_b) {
+                const float* src = rd_partial + (int64_t)(r0 + r) * Hp + n;
+                float sq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g0 = q * gq, g1 = g0 + gq < rd_G ? g0 + gq : rd_G;
+                    float z = 0.f;
+                    for (int g = g0; g < g1; ++g) z += src[(int64_t)g * rd_MH];
+                    sq[q] = z;
+                }
+                float c = rd_cvec8[n];
+#pragma unroll
+                for (int sl = 1; sl < 8; ++sl) c += rd_cvec8[sl * Hp + n];
+                v = elu_f((((sq[0] + sq[1]) + sq[2]) + sq[3]) + (c + rd_b1[n]));
+            }
+            act[r][n] = v;
+        }
+    } else {
+        for (int i = t; i < R * Hp; i += SF_THREADS) act[i / Hp][i % Hp] = a1_in[(int64_t)(r0 + i / Hp) * Hp + i % Hp];
+    }
     __syncthreads();
 
     // out[r][n] = sum_k in[r][k] * Wcur[k][n]: partial over this thread's k-group, reduced over groups later.
@@ -352,16 +382,18 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
 #define LAUNCH(N)                                                                                                  \
     hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,           \
                        (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,  \
-                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs, nblk, slot_rows);
+                       rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs, nblk, slot_rows,         \
+                       (const float*)nullptr, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa,
-                                      const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
-                                      const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8,
+                          const float* rd_b1, const float* Wh, const float* bh, const float* wa, const float* ba,
+                          const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows, const float* Y,
+                          float* yhat, float* dist, void* stream) {
     const loc_tuning* tune = nullptr;
     const int nblk = (n_b + SF_R - 1) / SF_R;
     // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups
@@ -377,11 +409,30 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
     hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
                        (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
-                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, 32);
+                       (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, 32, rd_partial, rd_G, rd_MH, rd_cvec8,  \
+                       rd_b1);
     SF_SWITCH(LAUNCH)
 #undef LAUNCH
     LOC_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, const float* wa,
+                                      const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
+                                      const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+    return sf_eval_launch(a1, nullptr, 0, 0, nullptr, nullptr, Wh, bh, wa, ba, wb, bb, Hp, L, n_b, rows, Y, yhat, dist, stream);
+}
+
+extern "C" int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t group_stride, const float* cvec8,
+                                              const float* b1, const float* Wh, const float* bh, const float* wa,
+                                              const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
+                                              const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+    if (!partial || groups < 1 || group_stride < (int64_t)n_b * Hp || !cvec8 || !b1) {
+        loc_set_error("loc_stack_forward_eval_partial: groups=%d group_stride=%lld n_b=%d", groups, (long long)group_stride, n_b);
+        return -1;
+    }
+    return sf_eval_launch(nullptr, partial, groups, group_stride, cvec8, b1, Wh, bh, wa, ba, wb, bb, Hp, L, n_b, rows, Y, yhat,
+                          dist, stream);
 }
 
 extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int use_drop, const float* acts,

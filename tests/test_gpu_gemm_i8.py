@@ -71,7 +71,7 @@ def decode_image(image, d, digits):
     raw = image.cpu().numpy()
     nkt = ((d.Kp + 63) // 64 + 1) & ~1
     delta = raw[8 * G8_HP * 4: 9 * G8_HP * 4].view(np.float32).copy()
-    tiles_off = (10 * G8_HP * 4 + nkt * G8_HP * 4 + 1023) // 1024 * 1024
+    tiles_off = (11 * G8_HP * 4 + nkt * G8_HP * 4 + 1023) // 1024 * 1024      # cvec8 | delta | colmax | guard | cpart | tiles
     t = raw[tiles_off: tiles_off + nkt * digits * G8_TILE].view(np.int8).reshape(nkt, digits, 4, G8_HP, 16)
     q = np.zeros((nkt, 4, G8_HP, 16), np.int64)
     for p in range(digits):
@@ -226,7 +226,8 @@ def test_predict_takes_the_int8_path_only_when_the_genotypes_allow_it():
         outs[name] = yhat.cpu().numpy()
         want = {"i8": net.lib.loc_l1_image_i8_bytes(C.byref(net.d), 3), "i8fast": net.lib.loc_l1_image_i8_bytes(C.byref(net.d), 2),
                 "bf16": net.lib.loc_l1_image_bytes(C.byref(net.d), 3)}[name]
-        assert net.l1_image is not None and net.l1_image.numel() == want
+        # (the exact mode runs under the dynamic-range guard, which may send the weights to the bf16 pieces: room for both)
+        assert net.l1_image is not None and net.l1_image.numel() >= want
         if name != "bf16":
             assert net.cnet().x_max == 2
     assert maxerr(outs["i8"], ref) < 2e-5 and maxerr(outs["bf16"], ref) < 2e-5
@@ -237,7 +238,7 @@ def test_predict_takes_the_int8_path_only_when_the_genotypes_allow_it():
     yhat = torch.zeros((n, 2), device="cuda")
     net.predict_rows(torch.arange(n, dtype=torch.int32, device="cuda"), n, yhat)
     torch.cuda.synchronize()
-    assert net.genotype_max() == 200 and net.l1_image.numel() == net.lib.loc_l1_image_bytes(C.byref(net.d), 3)
+    assert net.genotype_max() == 200 and net.l1_image.numel() >= net.lib.loc_l1_image_bytes(C.byref(net.d), 3)
     assert maxerr(yhat.cpu().numpy(), O.predict(p, x2)) < 2e-5
 
 
@@ -423,3 +424,28 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
     x2[3, 17] = 4
     net2 = build_net(x2, y, p)
     assert net2.pack_genotypes() is False and getattr(net2.X, "loc_x2", None) is None
+
+
+@pytest.mark.parametrize("n", [600, 1300, 3300])
+def test_group_reduction_fused_into_the_stack_launch_gives_the_same_bits(n):
+    """Default many-row predict: the int8 GEMM leaves its SNP-group partial sums and the hidden-stack launch adds them up in
+    its input stage (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial).  loc_tuning.gemm_reduce = 1 runs the
+    separate reduction launch instead: same association of the sums, so identical predictions and distances - for byte
+    genotypes and (3300 rows) for the 2-bit packed ones, two and three digit planes."""
+    K, width = 2500, 256
+    x, y, p, rng = make_problem(n, K, width, 4, seed=n)
+    outs = []
+    for digits in (3, 2):
+        pair = []
+        for tuning in ({}, {"gemm_reduce": 1}):
+            net = build_net(x, y, p, predict_digits=digits, tuning=tuning)
+            rows = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda() if not pair else pair[0][2]
+            yhat, dist = torch.zeros((n, 2), device="cuda"), torch.zeros(n, device="cuda")
+            net.predict_rows(rows, n, yhat, dist)
+            torch.cuda.synchronize()
+            pair.append((yhat.cpu().numpy(), dist.cpu().numpy(), rows))
+        assert np.array_equal(pair[0][0], pair[1][0]) and np.array_equal(pair[0][1], pair[1][1]), digits
+        outs.append(pair[0][0])
+    from oracle import locator_oracle as O
+    ref = O.predict(p, x[pair[0][2].cpu().numpy()])
+    assert maxerr(outs[0], ref) < 2e-5
