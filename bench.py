@@ -156,8 +156,12 @@ def _time_burst(fn, n=3, idle_s=0.25):
 # Predict modes the CLI ships (locator_amd/locator.py --predict_mode / --predict_pieces) and the bar each one is held to
 # on the PREDICTIONS at this workload's K (tests/test_gpu_baseline_sizes.py::test_config2_predict_all_rows):
 PREDICT_MODE_INFO = {
-    "int8x3": "default (--predict_mode exact): 24-bit fixed point per weight, predictions 2e-5 absolute / <= 1e-3 relative",
-    "int8x2": "--predict_mode fast: 16-bit fixed point per weight, predictions <= 1e-3 relative (north_star bound)",
+    "int8x3": "--predict_mode exact (and what the default takes when the dynamic-range guard refuses two planes): 24-bit fixed "
+              "point per weight, predictions 2e-5 absolute; tests/test_gpu_trained_predict.py: 8e-7 on converged fits",
+    "int8x2": "DEFAULT (--predict_mode auto) while the guard allows it (largest / typical scaled weight per unit: median <= 64, "
+              "worst <= 512; converged metric fit: 28 / 77): 16-bit fixed point per weight, predictions <= 1e-3 relative "
+              "(north_star bound), measured 5e-5 on the converged metric fit, 7e-5 on the reference's example fit "
+              "(tests/test_gpu_trained_predict.py); also --predict_mode fast (unconditional)",
     "bf16x3": "--predict_pieces 3 (and the fallback for genotypes > 127): fp32-exact products, 2e-5 absolute",
     "bf16x2": "--predict_pieces 2: predictions <= 1e-3 relative",
     "bf16x1": "--predict_pieces 1: plain bf16 weights, predictions only within 2e-2 - OUTSIDE the north_star tolerance, "
@@ -212,6 +216,34 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
             r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
             return r
 
+        def product_path(Xm, pitch, packed, image, digits, us_with_reduce):
+            """What loc_predict runs by default since round 4: the GEMM kernel WITHOUT its reduction launch
+            (loc_l1_forward_gemm_i8_partial) and the hidden-stack launch that adds the group partial sums up in its input
+            stage.  us_gemm_kernel = the GEMM alone; us_stack / us_stack_fused = the hidden-stack launch fed from a1 / from the
+            partial sums; us_layer1 = us_gemm_kernel + what the fusion adds to the stack launch = the layer-1 cost of the
+            product path, and frac_bf16_peak its fraction of the bf16 peak."""
+            groups, cv = C.c_int(0), C.c_void_p()
+            yh = torch.empty((n_rows, 2), device=dev)
+            runk = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_partial(Xm.data_ptr(), pitch, packed, rows.data_ptr(), n_rows,
+                                                                         C.byref(d), image.data_ptr(), digits, 2,
+                                                                         partial.data_ptr(), partial.numel(), 0, None,
+                                                                         C.byref(groups), C.byref(cv), st()))
+            runk()
+            mp = (n_rows + 127) // 128 * 128
+            args_tail = (P + 4 * lay.wh, P + 4 * lay.bh, P + 4 * lay.wa, P + 4 * lay.ba, P + 4 * lay.wb, P + 4 * lay.bb, d.Hp, d.L,
+                         n_rows, None, None, yh.data_ptr(), None, st)
+            run_s = lambda: _lib.check(lib.loc_stack_forward_eval(a1.data_ptr(), *args_tail[:-1], st()))
+            run_f = lambda: _lib.check(lib.loc_stack_forward_eval_partial(partial.data_ptr(), groups.value, mp * d.Hp, cv,
+                                                                         P + 4 * lay.b1, *args_tail[:-1], 0, st()))
+            us_k = _time_graphed(runk, iters)
+            it_s = max(3, iters // 4)
+            us_s, us_f = _time_graphed(run_s, it_s), _time_graphed(run_f, it_s)
+            us_l1 = us_k + max(0.0, us_f - us_s)
+            return {"us_gemm_kernel": round(us_k, 1), "groups": groups.value, "us_stack": round(us_s, 1),
+                    "us_stack_fused": round(us_f, 1), "us_layer1": round(us_l1, 1),
+                    "frac_bf16_peak": round(flops / us_l1 * 1e-6 / BF16_PEAK_TFLOPS, 4),
+                    "us_with_reduce_launch": us_with_reduce}
+
         for digits in (3, 2):
             if lib.loc_l1_gemm_i8_supported(d.Hp, digits):
                 image = torch.empty(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device=dev)
@@ -224,6 +256,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                 key = "int8x%d" % digits
                 out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
                 out[key]["tolerance"] = PREDICT_MODE_INFO[key]
+                out[key]["product_path"] = product_path(X, X.stride(0), 0, image, digits, out[key]["us"])
                 # the same GEMM reading a 2-bit packed copy of the matrix (--predict_packed / loc_net.X2; not the default:
                 # packing costs one pass over the matrix, see us_pack): bit-identical activations
                 X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
@@ -236,6 +269,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                                                                             partial.numel(), a1.data_ptr(), 0, None, st()))
                 keyp = key + "_packed2bit"
                 out[keyp] = timed(prep, runp, 0.5 * digits, n_rows * d.K / 4 + 1.0 * digits * d.K * d.H)
+                out[keyp]["product_path"] = product_path(X2, X2.stride(0), 1, image, digits, out[keyp]["us"])
                 out[keyp]["us_pack"] = round(_time_graphed(pack, 5), 1)
                 out[keyp]["tolerance"] = PREDICT_MODE_INFO[key] + "; --predict_packed: genotypes 0..3 stored 2 bits each (loc_pack_genotypes_2bit)"
                 del image, X2
@@ -263,6 +297,13 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
 
     res = shape(net.X, n_matrix, n_matrix)
     res["peak_tflops"] = BF16_PEAK_TFLOPS
+    g = net.quant_guard()
+    res["default_mode"] = {"flag": "--predict_mode auto (the CLI default)",
+                           "guard": {"median_range": round(g[0], 1), "max_range": round(g[1], 1)},
+                           "digit_planes": int(g[2]),
+                           "takes": ("int8x%d" % int(g[2]) if g[2] > 0 else "bf16x3") + ", from the 2-bit packed matrix for chunks of "
+                                    ">= 3072 rows (packed automatically when the genotypes are <= 3), group reduction fused into the "
+                                    "hidden-stack launch (product_path)"}
     res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
                      "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
     res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)

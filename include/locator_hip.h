@@ -100,6 +100,9 @@ typedef struct loc_tuning {
     int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
+    int stack_rows;       /* hidden stack of a many-row predict: 0 = default: 32 rows per workgroup on the fp32 matrix pipe from
+                             loc_stack_rows_min_rows() rows per chunk, 2 rows per workgroup on the vector ALU below; 1 = the
+                             matrix-pipe form for every chunk; -1 = never (measurement switch)                              */
     int gemm_reduce;      /* many-row predicts on the int8 pipe: 0 = default: the SNP-group sum + shift + b1 + ELU of the layer-1
                              GEMM happens in the input stage of the hidden-stack launch (no reduction launch, no a1 round
                              trip); 1 = the separate l1_gemm_reduce_kernel launch (same bits; measurement switch)               */
@@ -404,7 +407,17 @@ int loc_stack_forward_eval(const float* a1, const float* Wh, const float* bh, co
 int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t group_stride, const float* cvec8,
                                    const float* b1, const float* Wh, const float* bh, const float* wa, const float* ba,
                                    const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows,
-                                   const float* Y, float* yhat, float* dist, void* stream);
+                                   const float* Y, float* yhat, float* dist, int rows_form, void* stream);
+/* Both inference entry points take MANY rows (>= loc_stack_rows_min_rows(), padded width 256) through stack_rows.hip: 32 rows
+ * per workgroup on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: fp32 products and sums, the weights streamed once per 32
+ * rows) instead of 2 rows per workgroup on the vector ALU.  rows_form (loc_stack_forward_eval_form /
+ * loc_stack_forward_eval_partial; loc_tuning.stack_rows in loc_predict): 0 = by row count, 1 = always where supported,
+ * -1 = never.  Same arithmetic, different summation order: predictions agree to fp32 round-off (tests/test_gpu_stack_rows.py). */
+int loc_stack_rows_supported(int Hp, int L);
+int loc_stack_rows_min_rows(void);
+int loc_stack_forward_eval_form(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,
+                                const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows, const float* Y,
+                                float* yhat, float* dist, int rows_form, void* stream);
 /* ONE launch: dW, db + Adam for every hidden layer (one workgroup per 32x32 tile, W^T refreshed), head
  * gradients + Adam, and the batch-mean loss (to *loss_out). */
 int loc_stack_dw_adam(int Hp, int L, int n_pre, int n_b, int use_drop, const float* acts, const float* adrop,

@@ -40,7 +40,7 @@ class Layout(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("stack_helpers", C.c_int), ("stack_xcd_stride", C.c_int), ("l1b_nt_mask", C.c_int),
-                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("gemm_reduce", C.c_int), ("chain_tail", C.c_int)]
+                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("stack_rows", C.c_int), ("gemm_reduce", C.c_int), ("chain_tail", C.c_int)]
 
 
 class Net(C.Structure):
@@ -100,7 +100,10 @@ SIGNATURES = {
     "loc_l1_forward_gemm_i8_partial": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp,
                                                  C.c_int64, C.c_int, C.POINTER(Tuning), C.POINTER(C.c_int), C.POINTER(vp), vp]),
     "loc_stack_forward_eval_partial": (C.c_int, [vp, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int,
-                                                 C.c_int, vp, vp, vp, vp, vp]),
+                                                 C.c_int, vp, vp, vp, vp, C.c_int, vp]),
+    "loc_stack_rows_supported": (C.c_int, [C.c_int, C.c_int]),
+    "loc_stack_rows_min_rows": (C.c_int, []),
+    "loc_stack_forward_eval_form": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "loc_l1_forward_gemm_i8": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp, vp,
                                          C.c_int64, vp, C.c_int, C.POINTER(Tuning), vp]),
     "loc_genotype_max": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp]),

@@ -376,7 +376,8 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
                 TRY(loc_stack_forward_eval_partial(w.partial, groups, mp * Hp, cvec8, P + lay.b1, P + lay.wh, P + lay.bh,
                                                    P + lay.wa, P + lay.ba, P + lay.wb, P + lay.bb, Hp, L, nc,
                                                    with_targets ? rows + c0 : nullptr, with_targets ? net->Y : nullptr,
-                                                   yhat + 2 * (int64_t)c0, with_targets ? dist + c0 : nullptr, stream));
+                                                   yhat + 2 * (int64_t)c0, with_targets ? dist + c0 : nullptr,
+                                                   net->tune.stack_rows, stream));
                 continue;
             }
             if (i8 && net->X2 && net->x_max <= 3 && nc >= LOC_GEMM_I8_PACKED_MIN_ROWS)
@@ -400,10 +401,10 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
                 }
                 continue;
             }
-            TRY(loc_stack_forward_eval(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
-                                       P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
-                                       with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,
-                                       with_targets ? dist + c0 : nullptr, stream));
+            TRY(loc_stack_forward_eval_form(w.a1_rows, P + lay.wh, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
+                                            P + lay.bb, Hp, L, nc, with_targets ? rows + c0 : nullptr,
+                                            with_targets ? net->Y : nullptr, yhat + 2 * (int64_t)c0,
+                                            with_targets ? dist + c0 : nullptr, net->tune.stack_rows, stream));
         }
         return 0;
     }

@@ -393,7 +393,12 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
 static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8,
                           const float* rd_b1, const float* Wh, const float* bh, const float* wa, const float* ba,
                           const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows, const float* Y,
-                          float* yhat, float* dist, void* stream) {
+                          float* yhat, float* dist, void* stream, int rows_form = 0) {
+    // many rows: 32 rows per workgroup on the fp32 matrix pipe (stack_rows.hip) instead of 2 rows per workgroup on the
+    // vector ALU; rows_form: 0 = by row count, 1 = always (where supported), -1 = never (measurement / tests)
+    if (rows_form >= 0 && loc_stack_rows_supported(Hp, L) && (rows_form > 0 || n_b >= loc_stack_rows_min_rows()))
+        return sr_eval_launch(a1, rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist,
+                              stream);
     const loc_tuning* tune = nullptr;
     const int nblk = (n_b + SF_R - 1) / SF_R;
     // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups
@@ -422,17 +427,25 @@ extern "C" int loc_stack_forward_eval(const float* a1, const float* Wh, const fl
                                       const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
     return sf_eval_launch(a1, nullptr, 0, 0, nullptr, nullptr, Wh, bh, wa, ba, wb, bb, Hp, L, n_b, rows, Y, yhat, dist, stream);
 }
+extern "C" int loc_stack_forward_eval_form(const float* a1, const float* Wh, const float* bh, const float* wa,
+                                           const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
+                                           const int32_t* rows, const float* Y, float* yhat, float* dist, int rows_form,
+                                           void* stream) {
+    return sf_eval_launch(a1, nullptr, 0, 0, nullptr, nullptr, Wh, bh, wa, ba, wb, bb, Hp, L, n_b, rows, Y, yhat, dist, stream,
+                          rows_form);
+}
 
 extern "C" int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t group_stride, const float* cvec8,
                                               const float* b1, const float* Wh, const float* bh, const float* wa,
                                               const float* ba, const float* wb, const float* bb, int Hp, int L, int n_b,
-                                              const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+                                              const int32_t* rows, const float* Y, float* yhat, float* dist, int rows_form,
+                                              void* stream) {
     if (!partial || groups < 1 || group_stride < (int64_t)n_b * Hp || !cvec8 || !b1) {
         loc_set_error("loc_stack_forward_eval_partial: groups=%d group_stride=%lld n_b=%d", groups, (long long)group_stride, n_b);
         return -1;
     }
     return sf_eval_launch(nullptr, partial, groups, group_stride, cvec8, b1, Wh, bh, wa, ba, wb, bb, Hp, L, n_b, rows, Y, yhat,
-                          dist, stream);
+                          dist, stream, rows_form);
 }
 
 extern "C" int loc_stack_dw_adam_tail(int Hp, int L, int n_pre, int n_b, int slot_rows, int use_drop, const float* acts,

@@ -1,0 +1,167 @@
+// Hidden Dense(256, elu) layers + Dense(2) x 2 for MANY rows in inference mode (reference: model.predict on thousands of
+// rows - the batched --jacknife replicates, predictions over large sample sets, /root/reference/locator/locator.py:414,
+// :441, :683-747; layers :319-325).
+//
+// The row-parallel kernel of stack_fused.hip carries 2 rows per workgroup through the layers on the vector ALU and
+// re-streams all (L - 1) x 256 KB of weights from L2 for every pair of rows: right for a 32-row training step (16
+// workgroups, latency-bound) and for the 90-row validation sweep, but for 4096 rows it moves 4.8 GB through the L2 -> CU
+// ports and takes longer than the first-layer GEMM it follows (tools/predict_timeline.py, round 4: 235 us against 170 us at
+// 4096 rows x 100,000 SNPs; 800 against 640 at 16,384).  Here a workgroup takes 32 rows (one MFMA M tile) through every layer
+// on v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation - the same arithmetic as the vector-ALU kernel up to the
+// order of the sums - and streams the weights once per 32 rows (16 x less L2 traffic); activations never leave the LDS.
+//   wave w (of 8) owns output units [32 w, 32 w + 32) of every layer:  D[i = row][j = unit] += A[i][k] B[k][j], two k per
+//   MFMA: k = s + 128 hi for lane half hi, s = 0..127, so a lane's A values are CONSECUTIVE floats of its row in the LDS
+//   tile (one ds_read_b128 per four MFMAs) and its B values are W[k][32 w + jl]: two fully used 128-byte lines per request.
+//   Weight requests run 16 MFMAs (one register set) ahead, across layer boundaries (the weights do not depend on
+//   the activations).
+// Optional input stage as in stack_fused.hip: the many-row GEMM's SNP-group partial sums are added up here (+ shift + b1,
+// ELU), same association as l1_gemm_reduce_kernel.
+#include "common.h"
+
+#define SR_HP 256
+#define SR_ROWS 32
+#define SR_PITCH 260     /* floats per activation row in LDS: 16-lane ds_read_b128 groups start 4 banks apart */
+
+__device__ __forceinline__ void sr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512) void stack_rows_eval_kernel(
+    const float* __restrict__ a1, const float* __restrict__ rd_partial, int rd_G, int64_t rd_MH,
+    const float* __restrict__ rd_cvec8, const float* __restrict__ rd_b1, const float* __restrict__ Wh,
+    const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba, const float* __restrict__ wb,
+    const float* __restrict__ bb, int L, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
+    float* __restrict__ yhat, float* __restrict__ dist) {
+    constexpr int Hp = SR_HP, P = SR_PITCH;
+    extern __shared__ __attribute__((aligned(16))) float sr_smem[];        // two activation tiles + the head partials: 68.6 KB
+    float (*act)[SR_ROWS * P] = reinterpret_cast<float (*)[SR_ROWS * P]>(sr_smem);
+    float (*hp)[SR_ROWS][2] = reinterpret_cast<float (*)[SR_ROWS][2]>(sr_smem + 2 * SR_ROWS * P);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
+    const int r0 = blockIdx.x * SR_ROWS;
+    const int64_t HH = (int64_t)Hp * Hp;
+
+    // weight stream: chunk c of a layer = steps s = 16 c .. 16 c + 15, lane value W[(s + 128 hi) * Hp + 32 w + jl]
+    auto load_chunk = [&](const float* __restrict__ W, int c, float (&b)[16]) {
+        const float* p = W + (int64_t)(16 * c + 128 * hi) * Hp + 32 * w + jl;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b[e] = p[(int64_t)e * Hp];
+    };
+    float bA[16], bB[16];
+    load_chunk(Wh, 0, bA);
+    load_chunk(Wh, 1, bB);
+
+    // ---- input: rows of this workgroup -> act[0]
+    if (rd_partial != nullptr) {
+        const int gq = (rd_G + 3) / 4;
+        for (int i = t; i < SR_ROWS * Hp; i += 512) {
+            const int r = i / Hp, n = i % Hp;
+            float v = 0.f;
+            if (r0 + r < n_b) {
+                const float* src = rd_partial + (int64_t)(r0 + r) * Hp + n;
+                float sq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g0 = q * gq, g1 = g0 + gq < rd_G ? g0 + gq : rd_G;
+                    float z = 0.f;
+                    for (int g = g0; g < g1; ++g) z += src[(int64_t)g * rd_MH];
+                    sq[q] = z;
+                }
+                float c = rd_cvec8[n];
+#pragma unroll
+                for (int sl = 1; sl < 8; ++sl) c += rd_cvec8[sl * Hp + n];
+                v = elu_f((((sq[0] + sq[1]) + sq[2]) + sq[3]) + (c + rd_b1[n]));
+            }
+            act[0][r * P + n] = v;
+        }
+    } else {
+        for (int i = t; i < SR_ROWS * Hp; i += 512) {
+            const int r = i / Hp, n = i % Hp;
+            act[0][r * P + n] = r0 + r < n_b ? a1[(int64_t)(r0 + r) * Hp + n] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- layers 2..L
+    int cur = 0;
+    for (int l = 2; l <= L; ++l) {
+        const float* Wc = Wh + (int64_t)(l - 2) * HH;
+        const float* Wn = l < L ? Wc + HH : Wh;                // after the last layer: a dummy prefetch, never used
+        const float bias = bh[(int64_t)(l - 2) * Hp + 32 * w + jl];
+        const float* arow = act[cur] + jl * P + 128 * hi;      // this lane's row, its half of the k range
+        f32x16 acc = {0};
+#pragma unroll 1
+        for (int c = 0; c < 8; c += 2) {
+            {
+                f32x4 a4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + 16 * c + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc = mfma32(a4[e >> 2][e & 3], bA[e], acc);
+                if (c + 2 < 8) load_chunk(Wc, c + 2, bA); else load_chunk(Wn, 0, bA);
+            }
+            {
+                f32x4 a4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + 16 * (c + 1) + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc = mfma32(a4[e >> 2][e & 3], bB[e], acc);
+                if (c + 3 < 8) load_chunk(Wc, c + 3, bB); else load_chunk(Wn, 1, bB);
+            }
+        }
+        // bias + ELU -> the other activation buffer: lane holds unit 32 w + jl of rows rowmap(r, hi)
+        float* out = act[cur ^ 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[rowmap(r, hi) * P + 32 * w + jl] = elu_f(acc[r] + bias);
+        cur ^= 1;
+        sr_lds_barrier();
+    }
+    asm volatile("" ::"v"(bA[0]), "v"(bB[0]));
+
+    // ---- Dense(2), Dense(2), distance (locator.py:324-325, :314-315): per row, fixed summation order
+    {
+        const float* af = act[cur];
+        const int u = 32 * w + jl;
+        const float w0 = wa[2 * u], w1 = wa[2 * u + 1];
+        // lane (unit u, half hi) covers rows 16 hi .. 16 hi + 15: sum over the 32 units of this wave by lane shuffles
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 16 * hi + rr;
+            const float a = af[row * P + u];
+            float p0 = a * w0, p1 = a * w1;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+            if (jl == 0) { hp[w][row][0] = p0; hp[w][row][1] = p1; }
+        }
+        sr_lds_barrier();
+        if (t < SR_ROWS) {
+            const int b = r0 + t;
+            if (b < n_b) {
+                float y10 = ba[0], y11 = ba[1];
+                for (int w2 = 0; w2 < 8; ++w2) { y10 += hp[w2][t][0]; y11 += hp[w2][t][1]; }
+                const float y20 = y10 * wb[0] + y11 * wb[2] + bb[0];
+                const float y21 = y10 * wb[1] + y11 * wb[3] + bb[1];
+                yhat[2 * (int64_t)b] = y20;
+                yhat[2 * (int64_t)b + 1] = y21;
+                if (dist != nullptr && Y != nullptr) {
+                    const int64_t yr = rows[b];
+                    const float e0 = y20 - Y[2 * yr], e1 = y21 - Y[2 * yr + 1];
+                    dist[b] = sqrtf(fmaxf(e0 * e0 + e1 * e1, 0.f));
+                }
+            }
+        }
+    }
+}
+
+// rows from which the MFMA form beats the row-parallel vector-ALU kernel (128 workgroups of 32 rows; below that too few
+// workgroups to fill the chip, and a workgroup's nine dependent layers take ~60 us whatever the row count)
+extern "C" int loc_stack_rows_min_rows(void) { return 3072; }
+extern "C" int loc_stack_rows_supported(int Hp, int L) { return Hp == SR_HP && L >= 2; }
+
+int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8, const float* rd_b1,
+                   const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
+                   int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+    constexpr size_t lds = (2 * SR_ROWS * SR_PITCH + 8 * SR_ROWS * 2) * sizeof(float);
+    LOC_ENSURE_LDS(stack_rows_eval_kernel, lds);
+    hipLaunchKernelGGL(stack_rows_eval_kernel, dim3((n_b + SR_ROWS - 1) / SR_ROWS), dim3(512), lds, (hipStream_t)stream, a1,
+                       rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

@@ -406,6 +406,7 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
     matrix with a genotype above 3 is left unpacked."""
     x, y, p, rng = make_problem(700, 6000, 256, 4, seed=12)
     net = build_net(x, y, p)
+    net.auto_pack = False                      # since round 4 a many-row predict packs the matrix on its own: off for the reference pass
     rows = torch.from_numpy(rng.integers(0, 700, 4096).astype(np.int32)).cuda()
     out = {}
     for packed in (False, True):
@@ -424,6 +425,14 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
     x2[3, 17] = 4
     net2 = build_net(x2, y, p)
     assert net2.pack_genotypes() is False and getattr(net2.X, "loc_x2", None) is None
+    # the default: the first predict of >= 3072 rows packs the matrix itself (and a smaller one does not)
+    net3 = build_net(x, y, p)
+    yhat = torch.zeros((4096, 2), device="cuda")
+    net3.predict_rows(rows, 1000, yhat)
+    assert getattr(net3.X, "loc_x2", None) is None
+    net3.predict_rows(rows, 4096, yhat)
+    torch.cuda.synchronize()
+    assert getattr(net3.X, "loc_x2", None) is not None and np.array_equal(yhat.cpu().numpy(), out[(True, 4096)])
 
 
 @pytest.mark.parametrize("n", [600, 1300, 3300])
@@ -435,11 +444,11 @@ def test_group_reduction_fused_into_the_stack_launch_gives_the_same_bits(n):
     K, width = 2500, 256
     x, y, p, rng = make_problem(n, K, width, 4, seed=n)
     outs = []
+    rows = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
     for digits in (3, 2):
         pair = []
         for tuning in ({}, {"gemm_reduce": 1}):
             net = build_net(x, y, p, predict_digits=digits, tuning=tuning)
-            rows = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda() if not pair else pair[0][2]
             yhat, dist = torch.zeros((n, 2), device="cuda"), torch.zeros(n, device="cuda")
             net.predict_rows(rows, n, yhat, dist)
             torch.cuda.synchronize()
@@ -447,5 +456,5 @@ def test_group_reduction_fused_into_the_stack_launch_gives_the_same_bits(n):
         assert np.array_equal(pair[0][0], pair[1][0]) and np.array_equal(pair[0][1], pair[1][1]), digits
         outs.append(pair[0][0])
     from oracle import locator_oracle as O
-    ref = O.predict(p, x[pair[0][2].cpu().numpy()])
+    ref = O.predict(p, x[rows.cpu().numpy()])
     assert maxerr(outs[0], ref) < 2e-5
