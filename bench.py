@@ -217,11 +217,11 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
             return r
 
         def product_path(Xm, pitch, packed, image, digits, us_with_reduce):
-            """What loc_predict runs by default since round 4: the GEMM kernel WITHOUT its reduction launch
-            (loc_l1_forward_gemm_i8_partial) and the hidden-stack launch that adds the group partial sums up in its input
-            stage.  us_gemm_kernel = the GEMM alone; us_stack / us_stack_fused = the hidden-stack launch fed from a1 / from the
-            partial sums; us_layer1 = us_gemm_kernel + what the fusion adds to the stack launch = the layer-1 cost of the
-            product path, and frac_bf16_peak its fraction of the bf16 peak."""
+            """The alternative built and measured in round 4 (loc_tuning.gemm_reduce = 1; NOT the default, it is slower): the GEMM
+            kernel without its reduction launch (loc_l1_forward_gemm_i8_partial) and the hidden-stack launch adding the group
+            partial sums up in its input stage.  us_gemm_kernel = the GEMM alone; us_stack / us_stack_fused = the hidden-stack
+            launch (what follows the GEMM in a predict) fed from a1 / from the partial sums; us_layer1 = us_gemm_kernel + what
+            the fusion adds to the stack launch, to be read against us_with_reduce_launch (the default)."""
             groups, cv = C.c_int(0), C.c_void_p()
             yh = torch.empty((n_rows, 2), device=dev)
             runk = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_partial(Xm.data_ptr(), pitch, packed, rows.data_ptr(), n_rows,
@@ -256,7 +256,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                 key = "int8x%d" % digits
                 out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
                 out[key]["tolerance"] = PREDICT_MODE_INFO[key]
-                out[key]["product_path"] = product_path(X, X.stride(0), 0, image, digits, out[key]["us"])
+                out[key]["reduce_fused_into_stack"] = product_path(X, X.stride(0), 0, image, digits, out[key]["us"])
                 # the same GEMM reading a 2-bit packed copy of the matrix (--predict_packed / loc_net.X2; not the default:
                 # packing costs one pass over the matrix, see us_pack): bit-identical activations
                 X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
@@ -269,7 +269,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                                                                             partial.numel(), a1.data_ptr(), 0, None, st()))
                 keyp = key + "_packed2bit"
                 out[keyp] = timed(prep, runp, 0.5 * digits, n_rows * d.K / 4 + 1.0 * digits * d.K * d.H)
-                out[keyp]["product_path"] = product_path(X2, X2.stride(0), 1, image, digits, out[keyp]["us"])
+                out[keyp]["reduce_fused_into_stack"] = product_path(X2, X2.stride(0), 1, image, digits, out[keyp]["us"])
                 out[keyp]["us_pack"] = round(_time_graphed(pack, 5), 1)
                 out[keyp]["tolerance"] = PREDICT_MODE_INFO[key] + "; --predict_packed: genotypes 0..3 stored 2 bits each (loc_pack_genotypes_2bit)"
                 del image, X2
@@ -302,8 +302,8 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                            "guard": {"median_range": round(g[0], 1), "max_range": round(g[1], 1)},
                            "digit_planes": int(g[2]),
                            "takes": ("int8x%d" % int(g[2]) if g[2] > 0 else "bf16x3") + ", from the 2-bit packed matrix for chunks of "
-                                    ">= 3072 rows (packed automatically when the genotypes are <= 3), group reduction fused into the "
-                                    "hidden-stack launch (product_path)"}
+                                    ">= 3072 rows (packed automatically when the genotypes are <= 3); the hidden stack that follows takes the "
+                                    "fp32 matrix pipe from 3072 rows per chunk (us_stack)"}
     res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
                      "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
     res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)

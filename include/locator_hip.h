@@ -104,8 +104,11 @@ typedef struct loc_tuning {
                              loc_stack_rows_min_rows() rows per chunk, 2 rows per workgroup on the vector ALU below; 1 = the
                              matrix-pipe form for every chunk; -1 = never (measurement switch)                              */
     int gemm_reduce;      /* many-row predicts on the int8 pipe: 0 = default: the SNP-group sum + shift + b1 + ELU of the layer-1
-                             GEMM happens in the input stage of the hidden-stack launch (no reduction launch, no a1 round
-                             trip); 1 = the separate l1_gemm_reduce_kernel launch (same bits; measurement switch)               */
+                             GEMM is its own launch (l1_gemm_reduce_kernel); 1 = it happens in the input stage of the
+                             hidden-stack launch instead (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial: same
+                             bits, no reduction launch, no a1 round trip - built in round 4 and measured SLOWER: the few
+                             workgroups of the stack launch read the 33 MB of partial sums with less parallelism than the
+                             dedicated kernel, +17 us at 1000 rows and +30 us at 4096 against 8 us; kept as a switch)        */
     int chain_tail;       /* chained steps (loc_train_step_chain): 0 = default: the step's hidden-layer / head Adam tail runs
                              as trailing workgroups of the chained layer-1 launch (they fill the compute units that finish
                              their k-tiles an iteration early); -1 = its own launch after it (measurement switch)          */

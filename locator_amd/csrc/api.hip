@@ -364,8 +364,9 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
         }
         for (int c0 = 0; c0 < n; c0 += LOC_PREDICT_CHUNK) {
             const int nc = n - c0 < LOC_PREDICT_CHUNK ? n - c0 : LOC_PREDICT_CHUNK;
-            if (i8 && L >= 2 && net->tune.gemm_reduce == 0) {
-                // int8 GEMM -> hidden stack with the group reduction in the stack kernel's input stage
+            if (i8 && L >= 2 && net->tune.gemm_reduce == 1) {
+                // measurement switch: int8 GEMM -> hidden stack with the group reduction in the stack kernel's input stage
+                // (measured slower than the dedicated reduction launch, include/locator_hip.h)
                 const bool pk = net->X2 && net->x_max <= 3 && nc >= LOC_GEMM_I8_PACKED_MIN_ROWS;
                 int groups = 0;
                 const float* cvec8 = nullptr;

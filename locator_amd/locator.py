@@ -286,10 +286,19 @@ def load_network(traingen, dropout_prop, replicate=0, device="cuda:0"):
     return Model(traingen.shape[1], args.dropout_prop, args.width, args.nlayers, args._net_seed, replicate, device)
 
 
+_TLS = __import__("threading").local()
+
+
+def _out():
+    """Output stem of the fit this thread is running: a replicate unit's own stem while _fit_unit runs it (several units
+    may be fitting at once in one process, each on its own thread and stream), args.out otherwise."""
+    return getattr(_TLS, "out", None) or args.out
+
+
 def _weights_path(boot):
     if args.bootstrap or args.jacknife:
-        return args.out + "_boot" + str(boot) + ".weights.npz"
-    return args.out + ".weights.npz"
+        return _out() + "_boot" + str(boot) + ".weights.npz"
+    return _out() + ".weights.npz"
 
 
 def load_callbacks(boot):
@@ -376,12 +385,12 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
 
 def _predlocs_path(boot):
     if args.bootstrap or args.jacknife:
-        return f"{args.out}_boot{boot}_predlocs.txt"
+        return f"{_out()}_boot{boot}_predlocs.txt"
     if args.windows:
         # the reference appends the *flag* window to an --out that already carries the real window
         w0, wsize = int(args.window_start), int(args.window_size)
-        return f"{args.out}_{w0}-{w0 + wsize - 1}_predlocs.txt"
-    return args.out + "_predlocs.txt"
+        return f"{_out()}_{w0}-{w0 + wsize - 1}_predlocs.txt"
+    return _out() + "_predlocs.txt"
 
 
 def _to_map_units(z, sdlong, meanlong, sdlat, meanlat):
@@ -416,7 +425,7 @@ def predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pre
               f"median validation error {np.median(dists)}\n")
     if len(history.history.get("loss", [])):
         table = pd.DataFrame(history.history)
-        _write_atomic(args.out + "_history.txt", lambda fh: table.to_csv(fh, sep="\t", index=False))
+        _write_atomic(_out() + "_history.txt", lambda fh: table.to_csv(fh, sep="\t", index=False))
     return dists
 
 
@@ -439,6 +448,7 @@ def plot_history(history, dists):
 
 # ------------------------------------------------------------------ replicate units (windows / bootstrap)
 _BASE_CACHE = {}      # per worker process: the shared genotype rows, uploaded once per device
+_BASE_LOCK = __import__("threading").Lock()
 
 
 def _fit_unit(unit, device="cuda:0"):
@@ -479,13 +489,15 @@ def _fit_unit(unit, device="cuda:0"):
         tg, vg, pg = unit["traingen"], unit["testgen"], unit["predgen"]
         ntr, nva, npr, K = tg.shape[0], vg.shape[0], pg.shape[0], tg.shape[1]
         key = (device, id(tg), id(vg), id(pg)) if unit.get("cache_base") else None
-        X = _BASE_CACHE.get(key) if key else None
     if X is None:
-        X = upload_genotypes(np.concatenate([np.asarray(tg), np.asarray(vg), np.asarray(pg).reshape(npr, K)], axis=0),
-                             device)
-        if key:
-            _BASE_CACHE.clear()
-            _BASE_CACHE[key] = X
+        with _BASE_LOCK:                    # two fit threads of one process share the uploaded base matrix
+            X = _BASE_CACHE.get(key) if key else None
+            if X is None:
+                X = upload_genotypes(np.concatenate([np.asarray(tg), np.asarray(vg), np.asarray(pg).reshape(npr, K)], axis=0),
+                                     device)
+                if key:
+                    _BASE_CACHE.clear()
+                    _BASE_CACHE[key] = X
     if unit.get("site_order") is not None:
         X = gather_columns(X, unit["site_order"], K)
     phases["upload"] = time.time() - t_unit - phases["load"]
@@ -494,8 +506,7 @@ def _fit_unit(unit, device="cuda:0"):
     model = load_network(traingen, args.dropout_prop, replicate=unit["replicate"], device=device)
     # every file of this unit hangs off the unit's own stem (for a window: {out}_{start}-{end}; the reference swaps
     # args.out only after training, so its --keep_weights file is overwritten by every window)
-    original_out = args.out
-    args.out = unit["out"]
+    _TLS.out = unit["out"]              # thread-local: another unit may be fitting on another thread / stream of this process
     try:
         callbacks = load_callbacks(unit["boot"])
         t1 = time.time()
@@ -507,7 +518,7 @@ def _fit_unit(unit, device="cuda:0"):
                              unit["testlocs"], unit["pred"], unit["samples"], testgen, history, unit["boot"])
         phases["predict"] = time.time() - t1
     finally:
-        args.out = original_out
+        _TLS.out = None
     return {"name": unit["name"], "history": history.history, "dists": dists, "seconds": time.time() - t_unit,
             "phases": phases, "epochs": len(history.history.get("loss", []))}
 

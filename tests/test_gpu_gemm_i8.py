@@ -437,10 +437,11 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
 
 @pytest.mark.parametrize("n", [600, 1300, 3300])
 def test_group_reduction_fused_into_the_stack_launch_gives_the_same_bits(n):
-    """Default many-row predict: the int8 GEMM leaves its SNP-group partial sums and the hidden-stack launch adds them up in
-    its input stage (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial).  loc_tuning.gemm_reduce = 1 runs the
-    separate reduction launch instead: same association of the sums, so identical predictions and distances - for byte
-    genotypes and (3300 rows) for the 2-bit packed ones, two and three digit planes."""
+    """loc_tuning.gemm_reduce = 1: the int8 GEMM leaves its SNP-group partial sums and the hidden-stack launch adds them up in
+    its input stage (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial) instead of the dedicated reduction
+    launch of the default: same association of the sums, so identical predictions and distances - for byte genotypes and
+    (3300 rows) for the 2-bit packed ones and the matrix-pipe form of the stack, two and three digit planes.  (Measured slower
+    than the default, kept as a switch: include/locator_hip.h.)"""
     K, width = 2500, 256
     x, y, p, rng = make_problem(n, K, width, 4, seed=n)
     outs = []

@@ -42,7 +42,7 @@ def _run(net, a1_dev, n, form, with_dist):
     return yhat.cpu().numpy(), (dist.cpu().numpy() if with_dist else None)
 
 
-@pytest.mark.parametrize("n,width,nlayers", [(1, 256, 10), (31, 256, 10), (32, 256, 2), (33, 250, 4), (100, 256, 10),
+@pytest.mark.parametrize("n,width,nlayers", [(2, 256, 10), (31, 256, 10), (32, 256, 2), (33, 250, 4), (100, 256, 10),
                                              (3300, 256, 10), (4096, 230, 3)])
 def test_matrix_pipe_form_equals_the_vector_alu_form_and_the_oracle(n, width, nlayers):
     x, y, p, rng = make_problem(n, 300, width, nlayers, seed=n + nlayers)
