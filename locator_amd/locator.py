@@ -82,6 +82,10 @@ def build_parser():
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
     p.add_argument("--fits_per_gpu", default=2, type=int,
                    help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
+    p.add_argument("--procs_per_gpu", default=1, type=int,
+                   help="worker processes per GPU for --windows / --bootstrap (default 1): the --fits_per_gpu concurrent fits "
+                        "of a GPU run as that many threads of ONE process, each on its own stream - one device context, "
+                        "one start-up; --procs_per_gpu 2 with --fits_per_gpu 2 is the rounds 1-3 layout (one fit per process)")
     p.add_argument("--host_filter", default=False, action="store_true",
                    help="--windows: filter each window's SNPs on the host (NumPy) as rounds 1-3 did, instead of uploading "
                         "the raw calls and filtering on the device (same rows bit for bit; measurement / fallback switch)")
@@ -723,7 +727,8 @@ def main(argv=None):
         pool = replicates.ReplicatePool(args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu,
                                         host_prepare=_load_window_on_loader_thread if lazy_windows else None,
                                         unit_timeout=getattr(args, "unit_timeout", 0),
-                                        max_workers=_unit_count_bound()).start()
+                                        max_workers=_unit_count_bound(),
+                                        procs_per_gpu=getattr(args, "procs_per_gpu", 1)).start()
     try:
         return _main_body(pool, t_program)
     finally:

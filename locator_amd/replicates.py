@@ -73,7 +73,37 @@ def _attach(small, descs):
     return out, keep
 
 
-def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent):
+def _fit_stream(device):
+    """A HIP stream of this thread's own (several fits share one process and GPU, each on its own thread and stream)."""
+    import threading
+    tls = _fit_stream.__dict__.setdefault("tls", threading.local())
+    if getattr(tls, "stream", None) is None:
+        import torch
+        tls.stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") and torch.cuda.is_available() else False
+    return tls.stream
+
+
+def _run_on_own_stream(fit_fn, unit, shared, args, device, prepare):
+    """prepare + fit of one unit on the calling thread's stream."""
+    stream = _fit_stream(device)
+    try:
+        if stream:
+            import torch
+            with torch.cuda.stream(stream):
+                if prepare is not None:
+                    unit = prepare(unit)
+                r = _run_one(fit_fn, unit, shared, args, device)
+                stream.synchronize()
+                return r
+        if prepare is not None:
+            unit = prepare(unit)
+        return _run_one(fit_fn, unit, shared, args, device)
+    except Exception as e:                                   # noqa: BLE001 - e.g. prepare() raising
+        return {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
+                "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
+
+
+def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_threads=1):
     """Worker process on its own duplex pipe (no queue or lock is shared between workers, so one that is killed
     cannot wedge the others).  Start-up (import torch, device context, HIP library) happens right away - the parent
     spawns the pool BEFORE its own prologue so that the two overlap.  Messages in: ("shared", small, descs) once,
@@ -131,32 +161,40 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent):
             todo.put(("fatal", f"worker loader thread failed: {type(e).__name__}: {e}"))
 
     threading.Thread(target=loader, daemon=True).start()
-    while True:
-        item = todo.get()
-        if item is None:
-            break
-        if item[0] == "fatal":
-            try:
-                conn.send(("dead", item[1]))
-            except (OSError, ValueError):
-                pass
-            break
-        idx, unit, err, t_host = item
-        conn.send(("start", idx))
-        t1 = time.time()
-        if err is not None:
-            r = err
-        else:
-            try:
-                if prepare is not None:
-                    unit = prepare(unit)
-                r = _run_one(fit_fn, unit, box["shared"], args, device)
-            except Exception as e:                           # noqa: BLE001 - e.g. prepare() raising
-                r = {"name": unit.get("name", "?") if isinstance(unit, dict) else "?",
-                     "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
-        r["unit_index"], r["gpu"] = idx, gpu
-        r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t1
-        conn.send(("done", r))
+    send_lock = threading.Lock()
+
+    def send(msg):
+        with send_lock:
+            conn.send(msg)
+
+    def fit_loop():
+        # `fit_threads` of these run side by side: one process, one device context, one start-up - each fit on its own
+        # stream (a fit alternates between an HBM-bound phase and a latency-bound one; two of them interleave)
+        while True:
+            item = todo.get()
+            if item is None or item[0] == "fatal":
+                todo.put(item)                               # the siblings see it too
+                return
+            idx, unit, err, t_host = item
+            send(("start", idx))
+            t1 = time.time()
+            r = err if err is not None else _run_on_own_stream(fit_fn, unit, box["shared"], args, device, prepare)
+            r["unit_index"], r["gpu"] = idx, gpu
+            r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t1
+            send(("done", r))
+
+    fitters = [threading.Thread(target=fit_loop, daemon=True) for _ in range(max(1, int(fit_threads)) - 1)]
+    for th in fitters:
+        th.start()
+    fit_loop()
+    for th in fitters:
+        th.join()
+    last = todo.get()
+    if last is not None and last[0] == "fatal":
+        try:
+            send(("dead", last[1]))
+        except (OSError, ValueError):
+            pass
     for shm in box["keep"]:
         shm.close()
 
@@ -194,28 +232,42 @@ class ReplicatePool:
     two messages requeues the unit the same way."""
 
     def __init__(self, args, fit_fn, n_gpus=None, fits_per_gpu=1, prepare=None, host_prepare=None, log=print,
-                 poll_s=1.0, unit_timeout=0.0, max_workers=None):
+                 poll_s=1.0, unit_timeout=0.0, max_workers=None, procs_per_gpu=None):
+        """fits_per_gpu concurrent fits per GPU, run by procs_per_gpu worker processes per GPU (None = fits_per_gpu: one fit
+        per process, the rounds 1-3 layout) with ceil(fits_per_gpu / procs_per_gpu) fit threads each, every thread on its
+        own stream.  max_workers caps the CONCURRENT FITS (= the number of units, usually)."""
         import time
         self.args, self.fit_fn, self.prepare, self.host_prepare = args, fit_fn, prepare, host_prepare
         self.log, self.poll_s, self.unit_timeout = log, poll_s, float(unit_timeout or 0.0)
         n_vis = visible_gpus()
         self.n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
-        self.n = max(1, self.n_g * max(1, int(fits_per_gpu)))
-        if max_workers is not None:
-            self.n = max(1, min(self.n, int(max_workers)))
-        self.depth = 2 if host_prepare is not None else 1
+        fits = max(1, int(fits_per_gpu))
+        procs = fits if procs_per_gpu is None else max(1, min(int(procs_per_gpu), fits))
+        self.threads = -(-fits // procs)
+        if max_workers is not None:                     # never more concurrent fits than units
+            cap = max(1, int(max_workers))
+            while self.threads > 1 and self.n_g * procs * (self.threads - 1) >= cap:
+                self.threads -= 1
+            self.n = max(1, min(self.n_g * procs, -(-cap // self.threads)))
+        else:
+            self.n = max(1, self.n_g * procs)
+        self.fits = self.n * self.threads               # concurrent fits of the pool
+        self.depth = self.threads + (1 if host_prepare is not None else 0)
         self.workers = {}                   # parent end of the pipe -> state dict
         self.ctx = None
         self.t0 = time.time()
-        self.timeline = {"pool_created": self.t0, "workers": [], "units": {}, "n_workers": self.n, "n_gpus": self.n_g}
+        self.timeline = {"pool_created": self.t0, "workers": [], "units": {}, "n_workers": self.n, "n_gpus": self.n_g,
+                         "fit_threads": self.threads}
         self.failed_starts = 0
         self._slot = 0
 
     # ------------------------------------------------------------------ processes
     def start(self):
         """Spawn the workers now (no-op for a single in-process worker).  Returns self."""
-        if self.n <= 1 or self.workers:
+        if (self.n <= 1 and self.threads <= 1) or self.workers:
             return self
+        if self.n <= 1:
+            return self                     # one process = this one: run() drives the fit threads itself
         import torch.multiprocessing as mp
         self.ctx = mp.get_context("spawn")
         for w in range(self.n):
@@ -226,11 +278,11 @@ class ReplicatePool:
         import time
         a, b = self.ctx.Pipe(duplex=True)
         t = time.time()
-        p = self.ctx.Process(target=_worker, args=(gpu, self.fit_fn, self.args, self.prepare, self.host_prepare, b, t),
-                             daemon=True)
+        p = self.ctx.Process(target=_worker, args=(gpu, self.fit_fn, self.args, self.prepare, self.host_prepare, b, t,
+                                                   self.threads), daemon=True)
         p.start()
         b.close()                           # the parent keeps only its own end: EOF then means "the worker is gone"
-        self.workers[a] = {"p": p, "gpu": gpu, "inflight": [], "active": None, "t_active": 0.0, "ready": False,
+        self.workers[a] = {"p": p, "gpu": gpu, "inflight": [], "active": {}, "ready": False,
                            "shared_sent": False, "t_spawn": t, "slot": self._slot, "t_wait": t}
         self._slot += 1
 
@@ -242,39 +294,42 @@ class ReplicatePool:
         tl["run_started"] = time.time()
         out = [None] * len(units)
         if self.n <= 1 or len(units) <= 1 and not self.workers:
-            # one worker = this process; the host work of unit i + 1 still overlaps the fit of unit i (one loader thread)
+            # one worker process = this process: `threads` fit threads, each on its own stream, fed by ONE loader thread
+            # that prepares the host side of the next units (at most threads + 1 prepared-or-fitting at a time)
+            import threading
             from concurrent.futures import ThreadPoolExecutor
+            n_fit = max(1, min(self.threads, len(units)))
+            room = threading.Semaphore(n_fit + 1)
 
             def host(u):
+                room.acquire()
                 t1 = time.time()
                 try:
                     return (self.host_prepare(u, self.args) if self.host_prepare is not None else u), None, time.time() - t1
                 except Exception as e:                       # noqa: BLE001
                     return u, {"name": u.get("name", "?"), "error": f"{type(e).__name__}: {e}",
                                "traceback": traceback.format_exc()}, time.time() - t1
-            with ThreadPoolExecutor(1) as ex:
-                nxt = ex.submit(host, units[0]) if units else None
-                for i in range(len(units)):
-                    t1 = time.time()
-                    u, err, t_host = nxt.result()
-                    nxt = ex.submit(host, units[i + 1]) if i + 1 < len(units) else None
-                    t2 = time.time()
-                    if err is not None:
-                        r = err
-                    else:
-                        try:
-                            if self.prepare is not None:
-                                u = self.prepare(u)
-                            r = _run_one(self.fit_fn, u, shared, self.args, "cuda:0")
-                        except Exception as e:               # noqa: BLE001
-                            r = {"name": u.get("name", "?"), "error": f"{type(e).__name__}: {e}",
-                                 "traceback": traceback.format_exc()}
-                    r["unit_index"], r["gpu"] = i, 0
-                    r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t2
-                    out[i] = r
-                    tl["units"][i] = {"gpu": 0, "dispatched": t1, "started": t2, "done": time.time()}
-                    if "error" in r:
-                        self.log(f"replicate {r['name']} FAILED: {r['error']}")
+
+            def fit_one(i, fut):
+                t1 = time.time()
+                u, err, t_host = fut.result()
+                t2 = time.time()
+                try:
+                    r = err if err is not None else _run_on_own_stream(self.fit_fn, u, shared, self.args, "cuda:0", self.prepare)
+                finally:
+                    room.release()
+                r["unit_index"], r["gpu"] = i, 0
+                r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t2
+                out[i] = r
+                tl["units"][i] = {"gpu": 0, "dispatched": t1, "started": t2, "done": time.time()}
+                if "error" in r:
+                    self.log(f"replicate {r['name']} FAILED: {r['error']}")
+
+            with ThreadPoolExecutor(1) as ex_host, ThreadPoolExecutor(n_fit) as ex_fit:
+                hosts = [ex_host.submit(host, u) for u in units]
+                fits = [ex_fit.submit(fit_one, i, f) for i, f in enumerate(hosts)]
+                for f in fits:
+                    f.result()
             tl["run_finished"] = time.time()
             return out
         from collections import deque
@@ -336,11 +391,11 @@ class ReplicatePool:
             except OSError:
                 pass
             w["p"].join(5)
-            victim = w["active"] if w["active"] is not None else (w["inflight"][0] if w["inflight"] else None)
+            victims = set(w["active"]) if w["active"] else set(w["inflight"][:1])
             for i in w["inflight"]:
                 if out[i] is not None:
                     continue
-                if i == victim or attempts.get(i, 0) >= 2:
+                if i in victims or attempts.get(i, 0) >= 2:
                     record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": w["gpu"],
                             "error": f"worker process died ({why}, exit code {w['p'].exitcode}) while fitting this unit"})
                 else:
@@ -381,12 +436,13 @@ class ReplicatePool:
                         tl["workers"].append({"slot": w["slot"], "gpu": w["gpu"], "spawned": w["t_spawn"],
                                               "ready": info.pop("ready_at", time.time()), **info})
                     elif kind == "start":
-                        w["active"], w["t_active"] = payload, time.time()
-                        tl["units"].setdefault(payload, {})["started"] = w["t_active"]
+                        w["active"][payload] = time.time()
+                        tl["units"].setdefault(payload, {})["started"] = w["active"][payload]
                     elif kind == "done":
                         if payload["unit_index"] in w["inflight"]:
                             w["inflight"].remove(payload["unit_index"])
-                        w["active"], w["t_wait"] = None, time.time()
+                        w["active"].pop(payload["unit_index"], None)
+                        w["t_wait"] = time.time()
                         record(payload)
                     elif kind == "dead":
                         self.log(f"replicate worker on GPU {w['gpu']}: {payload}")
@@ -406,12 +462,13 @@ class ReplicatePool:
                     w = workers[conn]
                     if not w["p"].is_alive() and not conn.poll():
                         bury(conn, "not alive")
-                    elif self.unit_timeout and w["active"] is not None and now - w["t_active"] > self.unit_timeout:
-                        self.log(f"replicate {units[w['active']].get('name', '?')} on GPU {w['gpu']} exceeded "
+                    elif self.unit_timeout and w["active"] and now - min(w["active"].values()) > self.unit_timeout:
+                        slow = min(w["active"], key=w["active"].get)
+                        self.log(f"replicate {units[slow].get('name', '?')} on GPU {w['gpu']} exceeded "
                                  f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
                         w["p"].kill()               # this exact process
                         bury(conn, f"timed out after {self.unit_timeout:g} s")
-                    elif (self.unit_timeout and w["active"] is None and w["inflight"]
+                    elif (self.unit_timeout and not w["active"] and w["inflight"]
                           and now - w["t_wait"] > self.unit_timeout):
                         # nothing fitting, yet the next unit never reported "start": its host work (loader thread) hangs
                         self.log(f"replicate {units[w['inflight'][0]].get('name', '?')} on GPU {w['gpu']}: host work exceeded "
@@ -457,18 +514,18 @@ class ReplicatePool:
         ready = [w["ready"] for w in tl["workers"]]
         startup = [w.get("startup_seconds", 0.0) + w.get("spawn_seconds", 0.0) for w in tl["workers"]]
         first_ready = (min(ready) - t_prog) if ready else 0.0
-        n_w = max(1, min(self.n, len(recs)) if recs else self.n)
-        per_gpu = max(1, self.n // self.n_g)
+        n_w = max(1, min(self.fits, len(recs)) if recs else self.fits)
+        per_gpu = max(1, self.fits // self.n_g)
         serial = max(0.0, wall - work / n_w)
         s = {"wall_seconds": wall, "parent_prologue_seconds": t_run0 - t_prog, "dispatch_loop_seconds": t_run1 - t_run0,
-             "workers": self.n, "gpus": self.n_g, "worker_startup_seconds_mean": (sum(startup) / len(startup)) if startup else 0.0,
+             "workers": self.n, "fit_threads": self.threads, "gpus": self.n_g, "worker_startup_seconds_mean": (sum(startup) / len(startup)) if startup else 0.0,
              "first_worker_ready_after_seconds": first_ready, "units": len(recs), "unit_work_seconds": work,
              "host_prepare_seconds_total": host, "serial_seconds": serial, "serial_fraction": serial / wall if wall > 0 else 0.0,
              "amdahl_projection_seconds": {g: serial + work / (g * per_gpu) for g in (1, 2, 4, 8)}}
         s["amdahl_speedup_vs_1gpu"] = {g: s["amdahl_projection_seconds"][1] / v for g, v in s["amdahl_projection_seconds"].items()}
         s["lines"] = [
             f"replicate timeline: wall {wall:.1f} s = parent prologue {s['parent_prologue_seconds']:.1f} s + dispatch loop "
-            f"{s['dispatch_loop_seconds']:.1f} s; {self.n} worker(s) on {self.n_g} GPU(s), start-up "
+            f"{s['dispatch_loop_seconds']:.1f} s; {self.n} worker process(es) x {self.threads} fit thread(s) on {self.n_g} GPU(s), start-up "
             f"{s['worker_startup_seconds_mean']:.1f} s each (first one ready {first_ready:.1f} s after program start)",
             f"  {len(recs)} units: {work:.1f} s of worker time (host slices + filters {host:.1f} s on loader threads), "
             f"serial part {serial:.1f} s = {100 * s['serial_fraction']:.0f} % of the wall",
@@ -478,7 +535,7 @@ class ReplicatePool:
 
 
 def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print, fits_per_gpu=1, poll_s=1.0,
-              host_prepare=None, unit_timeout=0.0):
+              host_prepare=None, unit_timeout=0.0, procs_per_gpu=None):
     """Run every unit once; returns the result records in unit order (ReplicatePool started, run and closed here).
 
     units         list of dicts (small per-unit data; window units carry their window, not their genotypes)
@@ -486,7 +543,7 @@ def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=p
                   attached by every worker (the 0.5 GB bootstrap matrix is not pickled 16 times)"""
     pool = ReplicatePool(args, fit_fn, n_gpus=n_gpus, fits_per_gpu=fits_per_gpu, prepare=prepare,
                          host_prepare=host_prepare, log=log, poll_s=poll_s, unit_timeout=unit_timeout,
-                         max_workers=len(units))
+                         max_workers=len(units), procs_per_gpu=procs_per_gpu)
     try:
         return pool.run(units, shared)
     finally:

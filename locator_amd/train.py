@@ -183,7 +183,9 @@ class EpochRunner:
                 cur = torch.cuda.current_stream()
                 # capture is not allowed on the default stream: torch then captures on a side stream of its own
                 kw = {} if cur == torch.cuda.default_stream() else {"stream": cur}
-                with torch.cuda.graph(g, **kw):
+                # thread-local capture mode: another fit of this process (its own thread and stream, replicates.py) keeps
+                # allocating, synchronising and launching while this one captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
                     self.enqueue()
                 self.graph = g
             if self.graph is not None:
