@@ -268,7 +268,8 @@ class Model:
         rows = torch.arange(start, start + n, dtype=torch.int32, device=self.device)
         yhat = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
         net.predict_rows(rows, n, yhat)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()     # this fit's stream only: a device-wide wait would break into the graph
+        #                                               capture of another fit running on another thread of this process
         net.X = keepX
         net.cnet()
         return yhat.cpu().numpy()

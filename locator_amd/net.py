@@ -33,6 +33,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_NCU, _NCU_LOCK = {}, __import__("threading").Lock()
+
+
+def _compute_units(dev):
+    """Compute units of the device, asked once per process (fits on several threads of one process construct their nets at
+    the same time; torch's device-property query is not re-entrant on its first use)."""
+    key = str(dev)
+    with _NCU_LOCK:
+        if key not in _NCU:
+            _NCU[key] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        return _NCU[key]
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise _lib.LocatorHipError("locator_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback.")
@@ -93,7 +106,7 @@ class LocatorNet:
         self.wht = (torch.zeros((self.d.L - 1) * self.d.Hp * self.d.Hp, dtype=torch.float32, device=dev)
                     if self.use_fused else None)
         nkt = self.d.Kp // 32
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        ncu = _compute_units(dev)
         self.l1_fwd_grid = max(1, min(nkt, ncu, LOC_MAX_FWD_GRID))
         self.l1_bwd_grid = max(1, 2 * ncu)          # 2 blocks x 4 waves per CU, all resident
         self.predict_pieces = int(predict_pieces)

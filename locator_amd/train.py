@@ -16,6 +16,11 @@ import torch
 from .net import LocatorNet
 
 
+# HIP stream-capture mode of the epoch graphs.  Fits that share a process (replicates.py: one thread and stream each) capture
+# at different times, and the other thread keeps allocating, launching and waiting on events meanwhile.
+CAPTURE_ERROR_MODE = "thread_local"
+
+
 class Callbacks:
     """ModelCheckpoint(best only) -> EarlyStopping -> ReduceLROnPlateau on val_loss, in that order
     (locator.py:362).  All comparisons are strict '<' with min_delta 0 (locator.py:349-361)."""
@@ -185,7 +190,7 @@ class EpochRunner:
                 kw = {} if cur == torch.cuda.default_stream() else {"stream": cur}
                 # thread-local capture mode: another fit of this process (its own thread and stream, replicates.py) keeps
                 # allocating, synchronising and launching while this one captures
-                with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
                     self.enqueue()
                 self.graph = g
             if self.graph is not None:
