@@ -137,6 +137,7 @@ SIGNATURES = {
     "loc_train_chain_supported": (C.c_int, [C.POINTER(Net)]),
     "loc_train_step_chain": (C.c_int, [C.POINTER(Net), vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "loc_l1_chain_supported": (C.c_int, [C.c_int]),
+    "loc_l1_chain_groups_per_workgroup": (C.c_int, [C.c_int]),
     "loc_l1_backward_adam_chain": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, vp, vp] + [vp] * 12
                                    + [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.POINTER(Tuning), vp]),
     "loc_pack_genotypes_2bit": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int64, vp]),

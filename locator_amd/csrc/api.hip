@@ -116,17 +116,20 @@ static int max_rows_of(const loc_net* net) {
 
 // workgroups of the chained layer-1 kernel: one 8-wave workgroup where the plain backward runs two of 4 waves
 static int chain_grid_of(const loc_net* net) {
-    const int nkt = net->d.Kp / 32;
+    const int ktw = loc_l1_chain_groups_per_workgroup(net->d.Hp) > 0 ? loc_l1_chain_groups_per_workgroup(net->d.Hp) : 1;
+    const int nkt = net->d.Kp / 32, n_super = (nkt + ktw - 1) / ktw;      // a workgroup owns ktw k-tiles at a time
     int g = net->l1_bwd_grid / 2;
     if (g < 1) g = 1;
-    return g > nkt ? nkt : g;
+    return g > n_super ? n_super : g;
 }
+// layer-1 partial groups a chained step leaves for the reduction (workgroups x k-tile slots per workgroup)
+static int chain_groups_of(const loc_net* net) { return chain_grid_of(net) * loc_l1_chain_groups_per_workgroup(net->d.Hp); }
 
 extern "C" int loc_train_chain_supported(const loc_net* net) {
     const loc_dims* d = &net->d;
     const bool in_drop = net->drop_p > 0.f && d->n_pre == 0;
     return d->L >= 2 && net->wht && loc_stack_fused_supported(d->Hp) && loc_l1_chain_supported(d->Hp) &&
-           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_grid_of(net) <= LOC_MAX_FWD_GRID &&
+           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_groups_of(net) * 32 * d->Hp <= partial_floats_of(d) &&
            (int64_t)d->Kp * 1024 < ((int64_t)1 << 32) && (net->x_pitch % 16) == 0;
 }
 
@@ -175,7 +178,7 @@ static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int
     if (chain && fwd_done) {
         // the previous step's chained kernel left this minibatch's layer-1 partial sums: only add them up
         const bool dr = use_drop && npre == 1;
-        TRY(loc_l1_reduce_launch_drop(w.partial, chain_grid_of(net), 32, Hp, P + lay.b1, act(1), dr ? w.adrop : nullptr,
+        TRY(loc_l1_reduce_launch_drop(w.partial, chain_groups_of(net), 32, Hp, P + lay.b1, act(1), dr ? w.adrop : nullptr,
                                       dr ? mask : nullptr, ks, stream));
     } else if (n_b > LOC_ROWS) {
         // large-M forward, exact fp32 products (3 bf16 pieces); fills whole 128-row tiles of the activation slot
@@ -291,8 +294,8 @@ extern "C" int loc_train_step_chain(const loc_net* net, const int32_t* rows, int
                                     float* loss_out, const float* bn_next_stats, const int32_t* rows_next,
                                     int n_b_next, int fwd_done, void* ev_l1b0, void* ev_l1b1, void* stream) {
     if (!loc_train_chain_supported(net)) {
-        loc_set_error("loc_train_step_chain: needs width 225..256, nlayers >= 2, --batch_size <= 32 and no Dropout on the "
-                      "BatchNorm output (loc_train_chain_supported)");
+        loc_set_error("loc_train_step_chain: needs a width that pads to 64, 128 or 256, nlayers >= 2, --batch_size <= 32 and no "
+                      "Dropout on the BatchNorm output (loc_train_chain_supported)");
         return -1;
     }
     if (n_b > LOC_ROWS) { loc_set_error("loc_train_step_chain: n_b=%d out of 1..32", n_b); return -1; }

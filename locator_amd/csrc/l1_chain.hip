@@ -1,4 +1,6 @@
-// Layer-1 backward + Adam of minibatch t CHAINED with the layer-1 forward of minibatch t + 1, width 256
+// Layer-1 backward + Adam of minibatch t CHAINED with the layer-1 forward of minibatch t + 1; widths that pad to 256, 128 or
+// 64 (round 4: NHT = 8, 4, 2 unit tiles; a workgroup then owns 1, 2 or 4 k-tiles at a time so that all eight of its waves
+// stream weights whatever the width)
 // (reference: one `model.fit` step after another, /root/reference/locator/locator.py:367-376; layer 1 is
 // BatchNormalization + Dense(width, elu), :318-320).
 //
@@ -25,6 +27,16 @@
 // from that kernel (which forms sum_b dZ xhat and dxhat = dZ W^T with two MFMA chains): same sums, fp32 round-off differs;
 // against the fp64 oracle this association is the closer one (tests/chain_vs_oracle.py).
 // Trailing workgroups of the launch run the step's hidden-layer / head Adam tail (stack_tail.h).
+//
+// Narrower layers (round 4).  With NHT < 8 unit tiles a k-tile keeps only NHT waves busy, and the kernel lives on bytes in
+// flight per compute unit, so a workgroup owns KTW = 8 / NHT CONSECUTIVE k-tiles at a time (a
+// "super-tile"): wave w streams unit tile w % NHT of k-tile slot w / NHT.  Everything per k-tile - the small operands in
+// LDS, the cross-wave gamma / beta reduction (now over the NHT waves of a slot), the gamma / beta Adam, the next step's
+// scale / shift - exists once per slot; the 7 loader roles per slot are dealt round-robin over the 8 waves (1, 2 or 4 roles
+// per wave: more untracked small loads per wave, all OLDER than the 12 streaming loads the one hand-counted wait counts,
+// so the count stays 12).  A wave's forward accumulator covers its slot's k-tiles only, so the launch leaves KTW partial
+// groups per workgroup (partial[g * KTW + slot]) for l1_reduce_kernel.  The last super-tile may be short: its missing
+// slots run the same loads on dummy addresses, contribute zeros and store nothing.
 #include "common.h"
 #include "stack_tail.h"
 
@@ -81,11 +93,40 @@ __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4
                  : "memory");
 }
 
-constexpr int CH_HP = 256, CH_PZ = CH_HP + 1, CH_TP = 33;
+constexpr int CH_TP = 33;
 constexpr int CH_SM = 896;   // floats of one k-tile's small operands in LDS (see `sm` in the kernel)
-constexpr size_t CH_LDS_FLOATS = 32 * CH_PZ + 64 + 8 * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * CH_SM;
+constexpr size_t ch_lds_floats(int nht) {
+    return 32 * (nht * 32 + 1) + 64 + 8 * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * (8 / nht) * CH_SM;
+}
 
-template <int NTM>
+// The hand-counted wait: at most N vector-memory operations outstanding; the operands tie every register an untracked load
+// of this wave may still be writing (the current unit's three register sets and the small-operand words of its loader
+// roles), so no use of them can be scheduled above it.
+template <int N>
+__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], uint32_t (&ld)[1][3]) {
+    ch_wait_unit<N>(a, b, c, ld[0][0], ld[0][1], ld[0][2]);
+}
+template <int N>
+__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], uint32_t (&ld)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(%18)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[0][2]),
+                   "+v"(ld[1][0]), "+v"(ld[1][1]), "+v"(ld[1][2])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], uint32_t (&ld)[4][3]) {
+    asm volatile("s_waitcnt vmcnt(%24)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[0][2]),
+                   "+v"(ld[1][0]), "+v"(ld[1][1]), "+v"(ld[1][2]), "+v"(ld[2][0]), "+v"(ld[2][1]), "+v"(ld[2][2]),
+                   "+v"(ld[3][0]), "+v"(ld[3][1]), "+v"(ld[3][2])
+                 : "n"(N)
+                 : "memory");
+}
+
+template <int NTM, int NHT>
 __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b,
     const int32_t* __restrict__ rows_next, int n_b_next, int K, int Kp, float* bn4,
@@ -95,7 +136,11 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     float* __restrict__ b1, float* __restrict__ m_b1, float* __restrict__ v_b1, const float* __restrict__ alpha_tab,
     int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off,
     float* __restrict__ partial_out, int n_tail, loc_dw_tail_args ta) {
-    constexpr int NHT = 8, Hp = CH_HP, PZ = CH_PZ, TP = CH_TP;
+    constexpr int Hp = NHT * 32, PZ = Hp + 1, TP = CH_TP;
+    constexpr int KTW = 8 / NHT;                 // k-tiles (slots) a workgroup owns at a time
+    constexpr int NROLE = 7 * KTW;               // loader roles per super-tile
+    constexpr int RPW = (NROLE + 7) / 8;         // ... per wave
+    static_assert(NHT == 8 || NHT == 4 || NHT == 2, "unit tiles per k-tile");
     // Trailing workgroups (n_tail of them): the step's other Adam tail -- hidden-layer dW / db, heads, batch loss
     // (stack_tail.h).  It depends on nothing this kernel writes.  Workgroups are dispatched in index order, so these start
     // when the first layer-1 workgroups retire: 3125 k-tiles over 256 workgroups leave most compute units idle during the
@@ -103,7 +148,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     const int G = (int)gridDim.x - n_tail;
     if ((int)blockIdx.x >= G) {
         loc_gb_tail none = {};
-        stack_dw_all_body<8, 1>((int)blockIdx.x - G, ta, none);
+        stack_dw_all_body<NHT, 1>((int)blockIdx.x - G, ta, none);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -113,25 +158,28 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     float* Tt = reinterpret_cast<float*>(rown_l + 32);          // [8][32][TP] per-wave W' tile, [SNP][unit]
     float* red = Tt + 8 * 32 * TP;                              // [2][8][64]  per-wave (dgamma | dbeta) partials, by k-tile parity
     float* ssl = red + 2 * 8 * 64;                              // [8][64]     per-wave (scale' | shift') of the next step
-    // [2][CH_SM] the small operands of a k-tile, fetched two tiles ahead by seven loader waves (one to three load
-    // instructions each instead of 26 per wave): bytes 0..1023 genotype tile of this minibatch [32 rows][32 SNPs],
+    // [2][KTW][CH_SM] the small operands of a k-tile (slot), fetched two super-tiles ahead by the loader roles (one to three
+    // load instructions each instead of 26 per wave): bytes 0..1023 genotype tile of this minibatch [32 rows][32 SNPs],
     // 1024..2047 the same for the next minibatch, then floats [scale|shift|mean|rstd][32], (gamma|beta), their Adam
     // m, v [64] each, next [mean|var][32]
     float* sm = ssl + 8 * 64;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
-    const int nkt = Kp / KT;
+    const int ut = w % NHT, kq = w / NHT;        // this wave's unit tile, and its k-tile slot inside the super-tile
+    const int nkt = Kp / KT, S = (nkt + KTW - 1) / KTW;
+    // k-tile of slot `slot` of super-tile T, or -1 (no such super-tile, or past the end of a short last one)
+    auto ktile = [&](int T, int slot) { return (T >= 0 && T < S && T * KTW + slot < nkt) ? T * KTW + slot : -1; };
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
     const bool chain = rows_next != nullptr;
 
     // byte offset of this lane's first 16 bytes of unit (kt, w) in each of W1S / m / v  (Kp * 1024 < 2^32: checked by the launcher)
-    auto unit_off = [&](int kt) { return (uint32_t)(((uint32_t)kt * NHT + w) * 4096u + lane * 16u); };
+    auto unit_off = [&](int kt) { return (uint32_t)(((uint32_t)kt * NHT + ut) * 4096u + lane * 16u); };
     auto load_unit = [&](int kt, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
         // 12 loads, ALWAYS (the wait counts depend on it).  kt < 0: nothing left to fetch -- the same 12 instructions with
         // ONE address for the whole wave (one 16-byte request each instead of 1 KB), a different line per wave so that
         // the 2048 waves do not queue on one channel; results unused
-        const uint32_t o = kt >= 0 ? unit_off(kt) : (uint32_t)((((uint32_t)blockIdx.x * NHT + w) & 2047u) * 64u);
+        const uint32_t o = kt >= 0 ? unit_off(kt) : (uint32_t)((((uint32_t)blockIdx.x * 8 + w) & 2047u) * 64u);
         ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0>(vq[0], v1s, o);
         ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0>(vq[1], v1s, o);
         ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0>(vq[2], v1s, o);
@@ -139,7 +187,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     };
     // The first unit is requested before anything else; the prologue ends with vmcnt(0).
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
-    load_unit((int)blockIdx.x < nkt ? (int)blockIdx.x : -1, wA, mA, vA);
+    load_unit(ktile((int)blockIdx.x, kq), wA, mA, vA);
 
     for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
     if (t < 32) {
@@ -159,78 +207,92 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     __syncthreads();
     float dzs[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dzs[r] = red[w * 32 + rowmap(r, hi)];
+    for (int r = 0; r < 16; ++r) dzs[r] = red[ut * 32 + rowmap(r, hi)];
 
     // gamma (lanes 0..31) or beta (lanes 32..63) of SNP jl of the tile: one Adam per lane.  beta / m_beta / v_beta sit Kp
     // floats behind gamma / m_gamma / v_gamma (loc_param_layout; checked by the launcher): one wave-uniform base each
     const int gbo = hi * Kp;
     (void)beta; (void)m_beta; (void)v_beta;
-    // loader roles (wave-uniform): waves 0, 1 the genotype tile (8 bytes per lane), 2, 3 the next minibatch's, 4 bn4,
-    // 5 gamma / beta + moments, 6 the next minibatch's batch statistics.  fetch() issues the global loads of tile kt,
-    // stage() puts them into sm[buf] an iteration later (under load a small load takes about as long as a big one).
-    uint32_t ld0 = 0u, ld1 = 0u, ld2 = 0u;
-    auto fetch = [&](int kt) {
-        // three 4-byte loads per lane, ALWAYS; the role (and kt < 0: nothing left to fetch) only chooses the addresses
-        const int ktc = kt >= 0 ? kt : (int)blockIdx.x;
-        const int k = ktc * KT + jl;
-        const void *a0 = alpha_tab + w, *a1 = a0, *a2 = a0;            // wave 7, and every "nothing to fetch" case: one read-only word per wave
-        if (kt >= 0) {
-            if (w <= 3) {
-                const int pc = (w & 1) * 64 + lane;                   // 8-byte piece of the [32 rows][32 bytes] tile
-                const int row = w <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];      // (no next minibatch: row 0, unused)
-                const uint8_t* a = X + (int64_t)row * pitch + (int64_t)ktc * KT + 8 * (pc & 3);
-                a0 = a; a1 = a + 4; a2 = a;
-            } else if (w == 4) {
-                a0 = bn4 + (int64_t)hi * Kp + k; a1 = bn4 + (int64_t)(2 + hi) * Kp + k; a2 = a0;
-            } else if (w == 5) {
-                a0 = gamma + gbo + k; a1 = m_gamma + gbo + k; a2 = v_gamma + gbo + k;
-            } else if (w == 6 && chain) {
-                a0 = next_stats + (int64_t)hi * Kp + k; a1 = a0; a2 = a0;
-            }
-        }
-        ch_gload4(ld0, a0); ch_gload4(ld1, a1); ch_gload4(ld2, a2);
-    };
-    auto stage = [&](int buf) {
-        float* b = sm + buf * CH_SM;
-        if (w <= 1) {
-            // this minibatch's tile goes in TRANSPOSED, [SNP][32 bytes], the byte of row b at position
-            // 16 * ((b >> 2) & 1) + (b & 3) + 4 * (b >> 3): lane (SNP jl, half hi) then reads its 16 rows rowmap(r, hi),
-            // r = 0..15, as one 16-byte word
-            uint8_t* xb = reinterpret_cast<uint8_t*>(b);
-            const int pc = (w & 1) * 64 + lane, row = pc >> 2, snp0 = 8 * (pc & 3);
-            const int pos = 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3);
+    // loader roles (wave-uniform): role r = w + 8 rr (rr < RPW) serves slot r / 7 with kind r % 7: kinds 0, 1 the genotype
+    // tile (8 bytes per lane), 2, 3 the next minibatch's, 4 bn4, 5 gamma / beta + moments, 6 the next minibatch's batch
+    // statistics.  fetch() issues the global loads of super-tile T, stage() puts them into sm[buf] an iteration later (under
+    // load a small load takes about as long as a big one).
+    uint32_t ld[RPW][3];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xb[(snp0 + e) * 32 + pos] = (uint8_t)(((e < 4 ? ld0 : ld1) >> (8 * (e & 3))) & 255u);
-        } else if (w <= 3) {
-            uint2 v; v.x = ld0; v.y = ld1;
-            *reinterpret_cast<uint2*>(b + 256 + ((w & 1) * 64 + lane) * 2) = v;
-        } else if (w == 4) {
-            b[512 + lane] = bitsf(ld0);
-            b[576 + lane] = bitsf(ld1);
-        } else if (w == 5) {
-            b[640 + lane] = bitsf(ld0); b[704 + lane] = bitsf(ld1); b[768 + lane] = bitsf(ld2);
-        } else if (w == 6) {
-            b[832 + lane] = bitsf(ld0);
+    for (int rr = 0; rr < RPW; ++rr) ld[rr][0] = ld[rr][1] = ld[rr][2] = 0u;
+    auto fetch = [&](int T) {
+        // three 4-byte loads per role and lane, ALWAYS; the role (and "nothing to fetch") only chooses the addresses
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int role = w + 8 * rr, slot = role / 7, kind = role - 7 * slot;
+            const int kt = role < NROLE ? ktile(T, slot) : -1;
+            const int ktc = kt >= 0 ? kt : 0;
+            const int k = ktc * KT + jl;
+            const void *a0 = alpha_tab + w, *a1 = a0, *a2 = a0;        // every "nothing to fetch" case: one read-only word per wave
+            if (kt >= 0) {
+                if (kind <= 3) {
+                    const int pc = (kind & 1) * 64 + lane;             // 8-byte piece of the [32 rows][32 bytes] tile
+                    const int row = kind <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];   // (no next minibatch: row 0, unused)
+                    const uint8_t* a = X + (int64_t)row * pitch + (int64_t)ktc * KT + 8 * (pc & 3);
+                    a0 = a; a1 = a + 4; a2 = a;
+                } else if (kind == 4) {
+                    a0 = bn4 + (int64_t)hi * Kp + k; a1 = bn4 + (int64_t)(2 + hi) * Kp + k; a2 = a0;
+                } else if (kind == 5) {
+                    a0 = gamma + gbo + k; a1 = m_gamma + gbo + k; a2 = v_gamma + gbo + k;
+                } else if (kind == 6 && chain) {
+                    a0 = next_stats + (int64_t)hi * Kp + k; a1 = a0; a2 = a0;
+                }
+            }
+            ch_gload4(ld[rr][0], a0); ch_gload4(ld[rr][1], a1); ch_gload4(ld[rr][2], a2);
+        }
+    };
+    auto stage = [&](int buf, int T) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int role = w + 8 * rr, slot = role / 7, kind = role - 7 * slot;
+            if (role >= NROLE || ktile(T, slot) < 0) continue;
+            const uint32_t ld0 = ld[rr][0], ld1 = ld[rr][1], ld2 = ld[rr][2];
+            float* b = sm + (buf * KTW + slot) * CH_SM;
+            if (kind <= 1) {
+                // this minibatch's tile goes in TRANSPOSED, [SNP][32 bytes], the byte of row b at position
+                // 16 * ((b >> 2) & 1) + (b & 3) + 4 * (b >> 3): lane (SNP jl, half hi) then reads its 16 rows rowmap(r, hi),
+                // r = 0..15, as one 16-byte word
+                uint8_t* xb = reinterpret_cast<uint8_t*>(b);
+                const int pc = (kind & 1) * 64 + lane, row = pc >> 2, snp0 = 8 * (pc & 3);
+                const int pos = 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[(snp0 + e) * 32 + pos] = (uint8_t)(((e < 4 ? ld0 : ld1) >> (8 * (e & 3))) & 255u);
+            } else if (kind <= 3) {
+                uint2 v; v.x = ld0; v.y = ld1;
+                *reinterpret_cast<uint2*>(b + 256 + ((kind & 1) * 64 + lane) * 2) = v;
+            } else if (kind == 4) {
+                b[512 + lane] = bitsf(ld0);
+                b[576 + lane] = bitsf(ld1);
+            } else if (kind == 5) {
+                b[640 + lane] = bitsf(ld0); b[704 + lane] = bitsf(ld1); b[768 + lane] = bitsf(ld2);
+            } else {
+                b[832 + lane] = bitsf(ld0);
+            }
         }
     };
     {
-        const int kt = blockIdx.x;
-        fetch(kt < nkt ? kt : -1);
-        ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
-        if (kt < nkt) stage(0);
-        fetch(kt + G < nkt ? kt + G : -1);                      // staged during the first iteration
-        ch_wait_unit<0>(wA, mA, vA, ld0, ld1, ld2);
+        const int T0 = blockIdx.x;
+        fetch(T0);
+        ch_wait_unit<0>(wA, mA, vA, ld);
+        stage(0, T0);
+        fetch(T0 + G);                                          // staged during the first iteration
+        ch_wait_unit<0>(wA, mA, vA, ld);
     }
     __syncthreads();
 
-    // bias of layer 1: db1[h] = sum_b dZ[b][h]   (workgroup 0, wave w <-> unit tile w)
-    if (blockIdx.x == 0) {
+    // bias of layer 1: db1[h] = sum_b dZ[b][h]   (workgroup 0, the waves of slot 0: wave <-> unit tile)
+    if (blockIdx.x == 0 && kq == 0) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + w * 32 + jl];
+        for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ut * 32 + jl];
         s += __shfl_xor(s, 32);
         if (hi == 0) {
-            const int h = w * 32 + jl;
+            const int h = ut * 32 + jl;
             float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
             adam_update(wv, mv, vv, s, alpha);
             b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
@@ -245,11 +307,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 
     // Vector-memory operations of one iteration, in program order (the hand-counted wait depends on it):
     //   12 prefetch loads | wait | 12 stores of this unit | 3 small loads of tile + 2 | barrier | 0..5 small stores
-    auto step = [&](int kt, int kt_next, int kt_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
+    auto step = [&](int T, int T_next, int T_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
                     f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
+        const int ktv = ktile(T, kq);
+        const bool valid = ktv >= 0;             // false only for the missing slots of a short last super-tile (wave-uniform)
+        const int kt = valid ? ktv : 0;
         const int k = kt * KT + jl;
         // this tile's small operands from LDS
-        const float* smc = sm + par * CH_SM;
+        const float* smc = sm + (par * KTW + kq) * CH_SM;
         const uint8_t* xt = reinterpret_cast<const uint8_t*>(smc);
         const u32x4 xp = *reinterpret_cast<const u32x4*>(xt + jl * 32 + hi * 16);      // 16 rows of SNP jl, packed
         auto xv = [&](int r) { return (float)((xp[r >> 2] >> (8 * (r & 3))) & 255u); };
@@ -261,8 +326,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // ONE wait per iteration, right after the next unit's 12 loads (always 12: dummies on the last tile): "at most 12
         // outstanding" proves every older load landed -- this unit (requested an iteration ago) and the next tile's small
         // operands ld0..2 (requested at the end of the previous iteration).
-        load_unit(kt_next, wn, mn, vn);
-        ch_wait_unit<12>(wq, mq, vq, ld0, ld1, ld2);
+        load_unit(ktile(T_next, kq), wn, mn, vn);
+        ch_wait_unit<12>(wq, mq, vq, ld);
 
         // ONE fp32 MFMA chain per unit:  Gn[h][k] = sum_b dZ[b][h] xn[b][k]  (D[i = unit][j = SNP], contraction over the
         // batch rows b = rowmap(s, hi); xn = (x - mean) * rstd).  Everything else follows from it without forming dxhat
@@ -272,7 +337,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         //   sum_b dxhat[b][k]          = sum_h W[h][k] dzsum[h]                      (this wave's 32 units; old W)
         f32x16 g = {0};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + w * 32 + jl], (xv(s) - mu) * rs, g);
+        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ut * 32 + jl], (xv(s) - mu) * rs, g);
         {
             float pg = 0.f, pb = 0.f;
 #pragma unroll
@@ -282,7 +347,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             }
             pg += __shfl_xor(pg, 32);
             pb += __shfl_xor(pb, 32);
-            red[(par * 8 + w) * 64 + lane] = hi ? pb : pg;
+            red[(par * 8 + w) * 64 + lane] = valid ? (hi ? pb : pg) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = fmaf(gam, g[r], bet * dzs[r]);
@@ -304,39 +369,42 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 #if LOC_CHAIN_ABLATE & 32
         adam4(0); adam4(1); adam4(2); adam4(3);
 #else
+        // (stores never enter the load count - see the counting rule - so a missing slot may simply skip them)
+        if (!valid) { adam4(0); adam4(1); adam4(2); adam4(3); } else {
         adam4(0); ch_gstore16<0, (NTM & 4) != 0>(wq[0], w1s, so);    ch_gstore16<0, (NTM & 8) != 0>(mq[0], m1s, so);    ch_gstore16<0, (NTM & 8) != 0>(vq[0], v1s, so);
         adam4(1); ch_gstore16<1024, (NTM & 4) != 0>(wq[1], w1s, so); ch_gstore16<1024, (NTM & 8) != 0>(mq[1], m1s, so); ch_gstore16<1024, (NTM & 8) != 0>(vq[1], v1s, so);
         adam4(2); ch_gstore16<2048, (NTM & 4) != 0>(wq[2], w1s, so); ch_gstore16<2048, (NTM & 8) != 0>(mq[2], m1s, so); ch_gstore16<2048, (NTM & 8) != 0>(vq[2], v1s, so);
         adam4(3); ch_gstore16<3072, (NTM & 4) != 0>(wq[3], w1s, so); ch_gstore16<3072, (NTM & 8) != 0>(mq[3], m1s, so); ch_gstore16<3072, (NTM & 8) != 0>(vq[3], v1s, so);
+        }
 #endif
-        if (chain && !(LOC_CHAIN_ABLATE & 4)) {
+        if (chain && valid && !(LOC_CHAIN_ABLATE & 4)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tw[jl * TP + rowmap(r, hi)] = wq[r >> 2][r & 3];   // T[SNP][unit]
         }
         // The next tile's small operands (landed: see the wait above) go to the other LDS buffer, then the request for
         // the tile after next.
-        if (kt_next >= 0 && !(LOC_CHAIN_ABLATE & 2)) stage(par ^ 1);
-        fetch(kt_next2);
+        if (!(LOC_CHAIN_ABLATE & 2)) stage(par ^ 1, T_next);
+        fetch(T_next2);
 #if !(LOC_CHAIN_ABLATE & 1)
         // every wave's (dgamma | dbeta) partial of this k-tile and the next tile's small operands are in LDS; all reads
         // of this tile's small operands are above this line, so the buffer is free for tile + 2 after it
         ch_lds_barrier();
 #endif
 
-        float dsum = red[(par * 8 + 0) * 64 + lane];
+        float dsum = red[(par * 8 + kq * NHT) * 64 + lane];       // the NHT waves of this slot, in wave order
 #pragma unroll
-        for (int w2 = 1; w2 < 8; ++w2) dsum += red[(par * 8 + w2) * 64 + lane];
+        for (int w2 = 1; w2 < NHT; ++w2) dsum += red[(par * 8 + kq * NHT + w2) * 64 + lane];
         adam_update(pv, pm, pvv, dsum, alpha);
-        const bool live = k < K;
-        if (w == 0 && live) { gamma[gbo + k] = pv; m_gamma[gbo + k] = pm; v_gamma[gbo + k] = pvv; }
-        if (chain && !(LOC_CHAIN_ABLATE & 4)) {
+        const bool live = valid && k < K;
+        if (ut == 0 && live) { gamma[gbo + k] = pv; m_gamma[gbo + k] = pm; v_gamma[gbo + k] = pvv; }
+        if (chain && valid && !(LOC_CHAIN_ABLATE & 4)) {
             const float other = __shfl_xor(pv, 32);
             const float gam = hi ? other : pv, bet = hi ? pv : other;
             float rstd = 1.0f / sqrtf(nvar + BN_EPS);
             float scn = gam * rstd;
             float shn = bet - nmu * scn;
             if (!live) { scn = 0.f; shn = 0.f; nmu = 0.f; rstd = 0.f; }
-            if (w == 0) {
+            if (ut == 0) {
                 bn4[(hi ? Kp : 0) + k] = hi ? shn : scn;
                 bn4[(int64_t)(2 + hi) * Kp + k] = hi ? rstd : nmu;
             }
@@ -362,23 +430,26 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // workgroup g owns k-tiles g, g + G, g + 2G, ...: at any moment the G workgroups stream one contiguous G * 32 KB
     // window of W1 / m / v, which spreads over every HBM channel
     {
-        for (int kt = blockIdx.x; kt < nkt; kt += 2 * G) {
-            auto nx = [&](int j) { return kt + j * G < nkt ? kt + j * G : -1; };
-            step(kt, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
-            if (kt + G < nkt) step(kt + G, nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+        for (int T = blockIdx.x; T < S; T += 2 * G) {
+            auto nx = [&](int j) { return T + j * G < S ? T + j * G : -1; };
+            step(T, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+            if (T + G < S) step(T + G, nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
         }
     }
     // the last iteration's dummy requests are still in flight: nothing below may reuse their registers before they land
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (chain) {
         // D[i = row b][j = unit]: lane holds unit w*32 + jl, rows rowmap(r, hi) -- the layout l1_reduce_kernel sums
-        float* pout = partial_out + (int64_t)blockIdx.x * 32 * Hp;
+        // (one partial group per k-tile slot of this workgroup: group g * KTW + slot)
+        float* pout = partial_out + ((int64_t)blockIdx.x * KTW + kq) * 32 * Hp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + w * 32 + jl] = facc[r];
+        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + ut * 32 + jl] = facc[r];
     }
 }
 
-extern "C" int loc_l1_chain_supported(int Hp) { return Hp == CH_HP; }
+extern "C" int loc_l1_chain_supported(int Hp) { return Hp == 256 || Hp == 128 || Hp == 64; }
+// partial groups the chained kernel leaves per workgroup (k-tile slots a workgroup owns at a time)
+extern "C" int loc_l1_chain_groups_per_workgroup(int Hp) { return loc_l1_chain_supported(Hp) ? 8 / (Hp / 32) : 0; }
 
 int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
                                           const int32_t* rows_next, int n_b_next, const loc_dims* d, float* bn4,
@@ -388,7 +459,7 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
                                           const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                           int t_off, int grid, float* partial, int64_t partial_floats,
                                           const loc_tuning* tune, const loc_dw_tail_args* tail, void* stream) {
-    if (d->Hp != CH_HP) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 256 (got %d)", d->Hp); return -1; }
+    if (!loc_l1_chain_supported(d->Hp)) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 64, 128 or 256 (got %d)", d->Hp); return -1; }
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..32", n_b); return -1; }
     if (rows_next && (n_b_next < 1 || n_b_next > LOC_ROWS || !bn_next_stats)) {
         loc_set_error("loc_l1_backward_adam_chain: the next minibatch needs 1..32 rows (got %d) and its batch statistics",
@@ -408,37 +479,48 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
         loc_set_error("loc_l1_backward_adam_chain: more than 4M SNPs exceed the kernel's 32-bit byte offsets");
         return -1;
     }
-    const int nkt = d->Kp / KT;
+    const int nht = d->Hp / 32, ktw = 8 / nht;
+    const int nkt = d->Kp / KT, n_super = (nkt + ktw - 1) / ktw;
     if (grid < 1) grid = 1;
-    if (grid > nkt) grid = nkt;
-    if (rows_next && (int64_t)grid * 32 * CH_HP > partial_floats) {
-        loc_set_error("loc_l1_backward_adam_chain: partial buffer too small for %d workgroups", grid);
+    if (grid > n_super) grid = n_super;
+    if (rows_next && (int64_t)grid * ktw * 32 * d->Hp > partial_floats) {
+        loc_set_error("loc_l1_backward_adam_chain: partial buffer too small for %d workgroups x %d groups", grid, ktw);
         return -1;
     }
-    const size_t lds = CH_LDS_FLOATS * sizeof(float);
+    const size_t lds = ch_lds_floats(nht) * sizeof(float);
     // the step's hidden-layer / head Adam tail as trailing workgroups: (L - 1) * 64 weight tiles + the head block
     loc_dw_tail_args ta = {};
     int n_tail = 0;
     if (tail) {
         if (tail->n_b != n_b || tail->L < 2) { loc_set_error("loc_l1_backward_adam_chain: inconsistent tail arguments"); return -1; }
         ta = *tail;
-        n_tail = (tail->L - 1) * 64 + 1;
+        n_tail = (tail->L - 1) * nht * nht + 1;
     }
     const int ntm = !tune || tune->l1b_nt_mask == 0 ? 13 : (tune->l1b_nt_mask < 0 ? 0 : tune->l1b_nt_mask);
-#define LAUNCH_CHAIN(M)                                                                                            \
+#define LAUNCH_CHAIN_N(M, N)                                                                                       \
     {                                                                                                              \
-        LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M>), lds);                                                        \
-        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M>), dim3(grid + n_tail), dim3(512), lds, (hipStream_t)stream, X, \
+        LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M, N>), lds);                                                     \
+        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M, N>), dim3(grid + n_tail), dim3(512), lds, (hipStream_t)stream, X, \
                            x_pitch, rows, n_b, rows_next, n_b_next, d->K, d->Kp, bn4, bn_next_stats, dz1, w1s, m1s, v1s, \
                            gamma, beta, m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, \
                            t_base, t_off, partial, n_tail, ta);                                                    \
     }
-    switch (ntm) {
-        case 0: LAUNCH_CHAIN(0) break;
-        case 9: LAUNCH_CHAIN(9) break;
-        case 15: LAUNCH_CHAIN(15) break;
-        default: LAUNCH_CHAIN(13) break;
+#define LAUNCH_CHAIN(M)                                                                                            \
+    {                                                                                                              \
+        if (nht == 8) LAUNCH_CHAIN_N(M, 8) else if (nht == 4) LAUNCH_CHAIN_N(M, 4) else LAUNCH_CHAIN_N(M, 2)       \
     }
+    if (nht != 8) {                       // the cache-policy measurement switches exist for the default width only
+        LAUNCH_CHAIN(13)
+        LOC_CHECK_LAUNCH();
+        return 0;
+    }
+    switch (ntm) {
+        case 0: LAUNCH_CHAIN_N(0, 8) break;
+        case 9: LAUNCH_CHAIN_N(9, 8) break;
+        case 15: LAUNCH_CHAIN_N(15, 8) break;
+        default: LAUNCH_CHAIN_N(13, 8) break;
+    }
+#undef LAUNCH_CHAIN_N
 #undef LAUNCH_CHAIN
     LOC_CHECK_LAUNCH();
     return 0;

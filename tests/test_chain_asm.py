@@ -33,9 +33,9 @@ def _kernels(source, pattern):
     return res
 
 
-def _kernel_asm():
-    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13E")
-    assert len(ks) == 1, "kernel instantiation <13> not found in the assembly"
+def _kernel_asm(nht=8):
+    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13ELi%dEE" % nht)
+    assert len(ks) == 1, f"kernel instantiation <13, {nht}> not found in the assembly"
     return next(iter(ks.values()))
 
 
@@ -117,10 +117,14 @@ def _walk(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_counted_wait():
-    prog, lo, hi, n_loads, n_waits = _walk(_kernel_asm())
-    assert sum(1 for k, _, _ in prog[lo:hi + 1] if k == "aload") >= 2 * (12 + 3), "main loop with its 2 x (12 + 3) loads not found"
-    assert n_loads >= 3 * (12 + 3) and n_waits >= 4
+@pytest.mark.parametrize("nht", [8, 4, 2])
+def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_counted_wait(nht):
+    """Every width the chained kernel is built for (round 4: 8, 4, 2 unit tiles = widths padding to 256, 128, 64; a wave then
+    carries 1, 2 or 4 loader roles of 3 small loads each)."""
+    small = 3 * ((7 * (8 // nht) + 7) // 8)
+    prog, lo, hi, n_loads, n_waits = _walk(_kernel_asm(nht))
+    assert sum(1 for k, _, _ in prog[lo:hi + 1] if k == "aload") >= 2 * (12 + small), f"main loop with its 2 x (12 + {small}) loads not found"
+    assert n_loads >= 3 * (12 + small) and n_waits >= 4
     # the loop's waits are the pipelined ones, and the loop is drained before the epilogue reuses registers
     in_loop = [t for k, t, _ in prog[lo:hi + 1] if k == "await"]
     assert in_loop and all("vmcnt(12)" in t for t in in_loop), in_loop

@@ -62,8 +62,10 @@ def _run_epochs(x, y, p, tr, va, perms, chain, drop_p, use_graph, seed=5):
     (3000, 2, 40, 0.0),         # no dropout, one full + one 8-row minibatch
     (2000, 3, 64, 0.25),        # nlayers 3: Dropout directly on layer 1's output (mask applied by the reduction)
 ])
-def test_chained_epochs_equal_unchained_epochs(K, nlayers, n_train, drop_p):
-    width = 256
+@pytest.mark.parametrize("width", [256, 128, 100, 64, 40])
+def test_chained_epochs_equal_unchained_epochs(K, nlayers, n_train, drop_p, width):
+    """Widths padding to 256, 128 (100, 128) and 64 (40, 64): 8, 4, 2 unit tiles per k-tile; the narrower layers own 2 / 4
+    k-tiles per workgroup at a time (round 4; K = 5000 and 40010 leave a short last super-tile for both)."""
     x, y, p, rng = make_problem(n_train + 20, K, width, nlayers, seed=K % 97)
     tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
     perms = [np.random.default_rng(7 + e).permutation(n_train) for e in range(3)]
@@ -105,10 +107,11 @@ def test_chained_epochs_equal_unchained_epochs_at_config4_width_of_snps():
     assert np.abs(p1["W"][0] - p["W"][0]).max() > 1e-4 and np.abs(p1["W"][0][-40:] - p["W"][0][-40:]).max() > 1e-4   # trained, to the last SNP
 
 
-def test_chained_epochs_match_the_oracle_fit():
+@pytest.mark.parametrize("width", [256, 128, 64])
+def test_chained_epochs_match_the_oracle_fit(width):
     """Chained schedule against oracle.fit with the same permutations and the device's dropout masks: 4 epochs x 4
-    steps (last minibatch of 4 rows) at width 256.  Tolerances of test_short_fit_trajectory_matches_oracle_fit."""
-    K, width, nlayers = 2500, 256, 4
+    steps (last minibatch of 4 rows) at widths 256 / 128 / 64.  Tolerances of test_short_fit_trajectory_matches_oracle_fit."""
+    K, nlayers = 2500, 4
     x, y, p, rng = make_problem(130, K, width, nlayers, seed=33)
     tr, va, pr_rows = np.arange(0, 100), np.arange(100, 120), np.arange(120, 130)
     perms = [np.random.default_rng(100 + e).permutation(100) for e in range(4)]
@@ -128,9 +131,10 @@ def test_chained_epochs_match_the_oracle_fit():
     assert rel.max() < 1e-3, rel.max()
 
 
-def test_chained_graph_replay_equals_eager_enqueue():
+@pytest.mark.parametrize("width", [256, 128, 64])
+def test_chained_graph_replay_equals_eager_enqueue(width):
     """The captured epoch (graph replay) and the eagerly enqueued one run the same chained launches: bit-identical."""
-    K, width, nlayers = 3000, 256, 4
+    K, nlayers = 3000, 4
     x, y, p, rng = make_problem(90, K, width, nlayers, seed=3)
     tr, va = np.arange(70), np.arange(70, 90)
     perms = [np.random.default_rng(e).permutation(70) for e in range(3)]
@@ -142,10 +146,15 @@ def test_chained_graph_replay_equals_eager_enqueue():
 
 def test_chain_is_refused_where_it_does_not_apply():
     from locator_amd.train import EpochRunner
-    x, y, p, rng = make_problem(60, 500, 64, 4, seed=1)
+    x, y, p, rng = make_problem(60, 500, 300, 4, seed=1)
     net = build_net(x, y, p)
-    assert not net.chain_supported()                                    # width 64
+    assert not net.chain_supported()                                    # width 300 pads to 320: per-layer kernels
     assert not EpochRunner(net, np.arange(40), np.arange(40, 60), 32, chain=True).chain
+    x, y, p, rng = make_problem(60, 500, 512, 4, seed=1)
+    assert not build_net(x, y, p).chain_supported()                      # width 512: fused stack, unchained layer 1
+    for wdt in (64, 128):
+        x, y, p, rng = make_problem(60, 500, wdt, 4, seed=1)
+        assert build_net(x, y, p).chain_supported()                      # since round 4
     x, y, p, rng = make_problem(60, 500, 256, 1, seed=1)
     assert not build_net(x, y, p).chain_supported()                      # no hidden stack, Dropout on the BatchNorm output
     x, y, p, rng = make_problem(80, 500, 256, 4, seed=1)
@@ -157,6 +166,20 @@ def test_chain_is_refused_where_it_does_not_apply():
     net.set_batch(32)
     with pytest.raises(Exception, match="batch statistics"):
         net.train_step_chain(rows, 32, 1, torch.ones(32 * 256, dtype=torch.uint8, device="cuda"), loss, None, rows, 32, False)
+
+
+@pytest.mark.parametrize("width", [128, 64])
+def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps_narrow(width):
+    """100,000 SNPs at widths 128 / 64: 1563 / 782 super-tiles over 256 workgroups, every iteration of the pipeline in
+    steady state, the last super-tile short (3,125 k-tiles is odd)."""
+    K, nlayers, n_train = 100000, 10, 96
+    x, y, p, rng = make_problem(n_train + 20, K, width, nlayers, seed=width)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
+    perms = [np.random.default_rng(70 + e).permutation(n_train) for e in range(2)]
+    _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, 0.25, True)
+    _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, 0.25, True)
+    assert maxerr(h0, h1) < 2e-5, (h0, h1)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
 
 
 @pytest.mark.parametrize("K,n_b,n_b_next", [(4000, 32, 32), (4000, 17, 5), (9990, 32, 32), (100000, 32, 10)])
