@@ -70,10 +70,15 @@ __device__ __forceinline__ void ch_gload16(f32x4& v, const float* base, uint32_t
     if (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
 }
+// The two wait states behind the store are part of it: on gfx940+ a vector-memory store of more than 8 bytes still reads its
+// data registers for two wait states after it issues, and a vector-ALU write to them in that window corrupts what is
+// stored.  The compiler's hazard recognizer pads its OWN stores; it cannot see into an asm statement, and once the data
+// registers are dead after the asm it is free to reuse them at once - round 4's register allocation of the second step did
+// (`v_pk_add_f32 v[24:25]` right behind `global_store_dwordx4 v142, v[22:25]`: wrong Adam moments in memory, right weights).
 template <int OFF, bool NT>
 __device__ __forceinline__ void ch_gstore16(const f32x4& v, float* base, uint32_t voff) {
-    if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+    if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
 // 4 bytes at a per-lane 64-bit address
 __device__ __forceinline__ void ch_gload4(uint32_t& v, const void* p) {

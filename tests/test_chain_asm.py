@@ -113,6 +113,28 @@ def _walk(lines):
             for ltext, lregs in pending:
                 bad = regs & lregs
                 assert not bad, f"`{text}` touches v{sorted(bad)} while `{ltext}` is in flight"
+    # An asm store of more than 8 bytes keeps reading its data registers for two wait states after it issues (gfx940+ VMEM
+    # store-data hazard; the compiler pads its own stores, not an asm statement's): whatever follows an untracked store
+    # within two issue slots must be another store, a wait / nop, or must not WRITE the data registers.
+    for i, (kind, text, regs) in enumerate(prog):
+        if kind != "astore":
+            continue
+        data = _regs(re.split(r"[\s,]+", text)[2])
+        slots = 0
+        for k2, t2, r2 in prog[i + 1:]:
+            if k2 == "label":
+                continue
+            op = re.split(r"[\s,]+", t2)
+            if op[0] == "s_nop":
+                slots += int(op[1]) + 1
+            elif k2 in ("astore", "aload", "await") or op[0].startswith("s_"):
+                slots += 1
+            else:
+                dest = _regs(op[1]) if len(op) > 1 else set()
+                assert not (dest & data), f"`{t2}` writes v{sorted(dest & data)} {slots} wait state(s) behind `{text}`"
+                slots += 1
+            if slots >= 2:
+                break
     return prog, lo, hi, n_loads, n_waits
 
 
