@@ -104,32 +104,49 @@ __global__ __launch_bounds__(G8_HP) void l1_colmax_kernel(const float* __restric
 // guard[0] = median R over the real units (lower middle value), guard[1] = largest R, guard[2] = digit planes that hold
 // the tolerances of include/locator_hip.h (LOC_GUARD_*): 2, 3, or -1 = not even three (bf16 x 3 pieces: exact for any
 // weights), guard[3] = 3 or -1: the same decision when the caller insists on the exact mode.
-__global__ __launch_bounds__(G8_HP) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
-                                                               const float* __restrict__ sumabs_part, int nparts, int K, int H,
-                                                               float* __restrict__ guard) {
+__global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
+                                                              const float* __restrict__ sumabs_part, int nparts, int K, int H,
+                                                              float* __restrict__ guard) {
     __shared__ float R[G8_HP];
-    const int n = threadIdx.x;
-    float ss = 0.f;
-    for (int b = 0; b < nparts; ++b) ss += sumabs_part[(int64_t)b * G8_HP + n];
+    __shared__ float qs[4][G8_HP];
+    // 1024 threads: thread (q, n) adds the workgroup shares b = q, q + 4, ... of unit n with eight loads in flight (a single
+    // wave per unit walking 512 strided shares one after the other took 127 us); the four quarters, then the units'
+    // statistics, are combined in a fixed order
+    {
+        const int n = threadIdx.x & (G8_HP - 1), q = threadIdx.x >> 8;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = q;
+        for (; b + 28 < nparts; b += 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += sumabs_part[(int64_t)(b + 4 * e) * G8_HP + n];
+        }
+        for (int e = 0; b < nparts; b += 4, ++e) a[e & 7] += sumabs_part[(int64_t)b * G8_HP + n];
+        qs[q][n] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    __syncthreads();
+    // (every thread reaches the barriers below; the statistics are the first 256 threads' work)
+    const int n = threadIdx.x & (G8_HP - 1);
+    const bool first = threadIdx.x < G8_HP;
+    const float ss = (qs[0][n] + qs[1][n]) + (qs[2][n] + qs[3][n]);
     const float mx = bitsf(colmax[n]);
     const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
     const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
-    R[n] = r;
+    if (first) R[n] = r;
     __syncthreads();
     // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
     int rank = 0;
     for (int j = 0; j < H; ++j) rank += (R[j] < r || (R[j] == r && j < n)) ? 1 : 0;
     __shared__ float red[G8_HP];
-    red[n] = r;
+    if (first) red[n] = r;
     __syncthreads();
     for (int o = G8_HP / 2; o > 0; o >>= 1) {
-        if (n < o) red[n] = fmaxf(red[n], red[n + o]);
+        if (first && n < o) red[n] = fmaxf(red[n], red[n + o]);
         __syncthreads();
     }
     __shared__ float s_med;
-    if (n < H && rank == (H - 1) / 2) s_med = r;
+    if (first && n < H && rank == (H - 1) / 2) s_med = r;
     __syncthreads();
-    if (n == 0) {
+    if (threadIdx.x == 0) {
         const float rmed = s_med, rmax = red[0];
         guard[0] = rmed;
         guard[1] = rmax;
@@ -619,7 +636,7 @@ extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, co
     if (e != hipSuccess) { loc_set_error("loc_l1_quant_scan: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(l1_colmax_kernel, dim3(grid), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax, cpart);
     LOC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l1_quant_guard_kernel, dim3(1), dim3(G8_HP), 0, st, colmax, cpart, grid, d->K, d->H, guard);
+    hipLaunchKernelGGL(l1_quant_guard_kernel, dim3(1), dim3(1024), 0, st, colmax, cpart, grid, d->K, d->H, guard);
     LOC_CHECK_LAUNCH();
     return 0;
 }
