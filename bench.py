@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (no sparsity)
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")
 TRAFFIC_SOURCES = ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/l1_chain.hip", "locator_amd/csrc/common.h")
 
 

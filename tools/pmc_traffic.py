@@ -6,7 +6,8 @@ Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
   on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming
   read -> doubled for kernels whose reads are such streams (flagged per kernel below);
   WRITE_SIZE is uncalibrated by the guide -> calibrated here on a known byte count in the same run:
-  the ModelCheckpoint snapshot, a device-to-device copy of n_total floats (`__amd_rocclr_copyBuffer`).
+  the ModelCheckpoint snapshot, a device-to-device copy of n_total floats (`snapshot_if_kernel` since round 4; a torch
+  tensor copy, `__amd_rocclr_copyBuffer`, before).
 
 usage: pmc_traffic.py <fetch_dir>/f_counter_collection.csv <write_dir>/w_counter_collection.csv out.json [K H n]
 (tools/pmc_traffic.sh runs the two passes and this summary)
@@ -28,7 +29,8 @@ def kernel_sources_sha():
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     return h.hexdigest()[:16]
 
-WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_bwd_adam_chain_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer")
+WIDE_STREAM_READ = ("l1_bwd_adam_kernel", "l1_bwd_adam_chain_kernel", "l1_fwd_partial_kernel", "__amd_rocclr_copyBuffer",
+                    "snapshot_if_kernel")
 
 
 def per_kernel(path, counter):
@@ -55,7 +57,10 @@ def main():
                   "traffic_bytes": rd + w_mean * 1024, "FETCH_max": max(f), "WRITE_max": max(w)}
     K, H, n = (int(v) for v in sys.argv[4:7]) if len(sys.argv) >= 7 else (100000, 256, 1000)
     n_total = None
-    cal = out.get("__amd_rocclr_copyBuffer")
+    # round 4: the ModelCheckpoint snapshot is the predicated device copy snapshot_if_kernel (the epochs that improve val_loss
+    # copy all n_total parameters: its largest launch); before, a torch tensor copy (__amd_rocclr_copyBuffer)
+    cal_name = next((k for k in out if k.startswith("snapshot_if_kernel")), "__amd_rocclr_copyBuffer")
+    cal = out.get(cal_name)
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 "
                      "bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-l1-gemm --no-graph; tools/pmc_traffic.sh",
            "workload": {"K": K, "H": H, "n": n},
@@ -63,8 +68,8 @@ def main():
            "units": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled for wide (16 B/lane) streaming reads per "
                     "MI355X_MICROARCH.md (HBM section)",
            "calibration": None if cal is None else {
-               "kernel": "__amd_rocclr_copyBuffer: the largest copy is the ModelCheckpoint snapshot, a device-to-device "
-                         "copy of all n_total parameters",
+               "kernel": cal_name + ": its largest launch is the ModelCheckpoint snapshot, a device-to-device copy of all "
+                                    "n_total parameters",
                "WRITE_SIZE_KiB_max": cal["WRITE_max"], "FETCH_SIZE_KiB_max": cal["FETCH_max"],
                "fetch_over_write": cal["FETCH_max"] / cal["WRITE_max"] if cal["WRITE_max"] else None,
                "note": "a copy reads what it writes: WRITE_SIZE equals the buffer size and FETCH_SIZE reports 1/2 of it "

@@ -10,7 +10,7 @@
 #   gpurun_out/<tag>_gemm_pmc_1000.json, _4096.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters (with the effective
 #                                                 clock from GRBM_GUI_ACTIVE) and kernel times, int8 and bf16 kernels
 # Copy what should be judged into profiles/ (tracked).
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -37,6 +37,15 @@ rm -rf $O/gemm_kt
 rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000,4096 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
 cp $O/gemm_kt/k_kernel_stats.csv $O/${TAG}_gemm_kernel_stats.csv
 python3 $R/tools/rows_gemm_bench.py --rows 4096,16384 --iters 10 --i8-only --packed >> $O/${TAG}_gemm_bench.log 2>&1    # 2-bit packed genotypes
+# round 4 evidence: trained-weight tolerance of the predict modes, quantisation study, fit timelines, predict timeline
+cd $R
+python3 -m pytest tests/test_gpu_trained_predict.py -q -s > $O/${TAG}_trained_predict.log 2>&1
+python3 tools/quant_study.py --out $O/${TAG}_quant_study.jsonl > $O/quant_study.log 2>&1
+bash tools/config1_timeline.sh ${TAG} > $O/config1_timeline.log 2>&1
+bash tools/config1_timeline.sh ${TAG}sync --sync >> $O/config1_timeline.log 2>&1
+python3 tools/predict_timeline.py --mode auto > $O/${TAG}_predict_timeline.jsonl 2>/dev/null
+for w in 128 64; do python3 bench.py --steps 20 --warmup 4 --width $w --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_width$w.json 2>/dev/null; python3 bench.py --steps 20 --warmup 4 --width $w --no-chain --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_width${w}_unchained.json 2>/dev/null; done
+python3 bench.py --steps 40 --warmup 5 --sync-epochs --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_sync_epochs.json 2>/dev/null
 tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
 tail -6 $O/pmc_traffic.log; tail -4 $O/gemm_pmc.log | cut -c1-400
