@@ -88,13 +88,20 @@ __device__ __forceinline__ void ch_gload4(uint32_t& v, const void* p) {
 // no use of them can be scheduled above it.  COUNTING RULE (gfx9 has one counter for loads and stores): loads retire in
 // order among loads and stores among stores, but a store may retire before an older load.  So "at most N outstanding"
 // proves that a load has landed only if N is the number of LOADS issued after it -- stores never count.
+// (a -DLOC_CHAIN_DEBUG_DRAIN build - `make debug_drain`, the parity-debug twin library - turns every hand count into
+// vmcnt(0); tests/test_gpu_chain.py compares the two builds bit for bit)
+#ifdef LOC_CHAIN_DEBUG_DRAIN
+#define CH_VMCNT(N) 0
+#else
+#define CH_VMCNT(N) (N)
+#endif
 template <int N>
 __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], uint32_t& s0, uint32_t& s1,
                                              uint32_t& s2) {
     asm volatile("s_waitcnt vmcnt(%15)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
                    "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(s0), "+v"(s1), "+v"(s2)
-                 : "n"(N)
+                 : "n"(CH_VMCNT(N))
                  : "memory");
 }
 
@@ -117,7 +124,7 @@ __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
                    "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[0][2]),
                    "+v"(ld[1][0]), "+v"(ld[1][1]), "+v"(ld[1][2])
-                 : "n"(N)
+                 : "n"(CH_VMCNT(N))
                  : "memory");
 }
 template <int N>
@@ -127,7 +134,7 @@ __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4
                    "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(ld[0][0]), "+v"(ld[0][1]), "+v"(ld[0][2]),
                    "+v"(ld[1][0]), "+v"(ld[1][1]), "+v"(ld[1][2]), "+v"(ld[2][0]), "+v"(ld[2][1]), "+v"(ld[2][2]),
                    "+v"(ld[3][0]), "+v"(ld[3][1]), "+v"(ld[3][2])
-                 : "n"(N)
+                 : "n"(CH_VMCNT(N))
                  : "memory");
 }
 

@@ -273,3 +273,49 @@ def test_chain_kernel_against_the_two_kernels_it_replaces(K, n_b, n_b_next):
     assert np.abs(a["P"][sl(lay.w1, Hp * Kp)] - P0.cpu().numpy()[sl(lay.w1, Hp * Kp)]).max() > 1e-4     # it did train
     np.testing.assert_allclose(b["bn4"], a["bn4"], rtol=2e-6, atol=2e-6)      # rstd reaches 1 / sqrt(BN eps) = 31.6
     assert maxerr(a["a1"][:n_b_next], b["a1"][:n_b_next]) < 2e-5 * max(1.0, float(np.abs(a["a1"]).max()))
+
+
+_CHAIN_BITCMP = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[2])
+if sys.argv[1] != "-":
+    from locator_amd import _lib
+    _lib.use_library(sys.argv[1])
+import torch
+from tests.gpu_util import build_net, make_problem
+from locator_amd.train import EpochRunner
+h = hashlib.sha256()
+for width, K in ((256, 40010), (128, 20000), (64, 9000)):
+    x, y, p, rng = make_problem(116, K, width, 4, seed=width)
+    net = build_net(x, y, p, drop_p=0.25, seed=5)
+    r = EpochRunner(net, np.arange(96), np.arange(96, 116), 32, use_graph=False, chain=True)
+    for e in range(2):
+        l, v = r.run_epoch(np.random.default_rng(7 + e).permutation(96))
+        h.update(np.float64([l, v]).tobytes())
+    torch.cuda.synchronize()
+    h.update(net.params.cpu().numpy().tobytes()); h.update(net.adam_m.cpu().numpy().tobytes()); h.update(net.adam_v.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_hand_counted_wait_of_the_chained_kernel_equals_its_drained_build_bit_for_bit(tmp_path):
+    """the chained kernel's streaming loads are untracked asm with ONE hand-counted wait per iteration.  The
+    parity-debug twin library (`make debug_drain`, part of build()) compiles it with every count replaced by vmcnt(0); two
+    chained epochs at each width (several k-tiles per workgroup, a short last super-tile) must leave identical losses,
+    weights and Adam moments.  Separate processes: one library per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drain = os.path.join(root, "locator_amd", "liblocator_hip_drain.so")
+    if not os.path.exists(drain):
+        pytest.skip("locator_amd/liblocator_hip_drain.so not built (make -C locator_amd/csrc debug_drain)")
+    script = tmp_path / "chain_bitcmp.py"
+    script.write_text(_CHAIN_BITCMP)
+    out = []
+    for lib in ("-", drain):
+        r = subprocess.run([sys.executable, str(script), lib, root], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert out[0] == out[1], out
