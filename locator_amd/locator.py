@@ -149,7 +149,8 @@ def _setup(argv=None):
 def _write_atomic(path, writer, mode="w"):
     """Write through a temporary file in the same directory and rename it into place: concurrent replicate workers
     (and a reader of a half-finished run) never see a truncated file."""
-    tmp = f"{path}.tmp{os.getpid()}"
+    import threading
+    tmp = f"{path}.tmp{os.getpid()}_{threading.get_ident()}"     # replicate fits may share a process (one thread each)
     with open(tmp, mode) as fh:
         writer(fh)
     os.replace(tmp, path)
@@ -378,9 +379,12 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
                              "genotypes and filters (--min_mac, --max_SNPs, --impute_missing), --width and --nlayers")
         history = History()
     else:
+        from . import replicates
+        # fits that share this process with other fit threads launch their epochs eagerly (replicates._FIT_THREADS)
+        use_graph = not args.no_graph and replicates.fit_threads_in_process() <= 1
         history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
                       max_epochs=args.max_epochs, patience=earlystop["patience"], lr_patience=reducelr["patience"],
-                      lr_factor=reducelr["factor"], use_graph=not args.no_graph, verbose=args.keras_verbose,
+                      lr_factor=reducelr["factor"], use_graph=use_graph, verbose=args.keras_verbose,
                       chain=False if getattr(args, "no_chain", False) else None)
     if args.keep_weights:
         save_weights(checkpointer["filepath"], model.weights_dict())

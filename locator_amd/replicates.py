@@ -73,6 +73,18 @@ def _attach(small, descs):
     return out, keep
 
 
+# Fit threads of THIS process (set by the worker / the in-process path before the first fit starts).  Fits that share a
+# process do not capture HIP graphs: capture is process-sensitive on this platform even in thread-local mode - another
+# thread's device-wide wait, or a garbage-collection pass that frees a graph or an event while a capture is open, aborts
+# the process (observed: `Fatal Python error: Aborted` in a 2-replicate --bootstrap, tests/test_gpu_cli.py).  With the
+# callbacks on the device and epochs enqueued ahead, an eagerly launched epoch costs host time, not GPU time.
+_FIT_THREADS = 1
+
+
+def fit_threads_in_process():
+    return _FIT_THREADS
+
+
 def _fit_stream(device):
     """A HIP stream of this thread's own (several fits share one process and GPU, each on its own thread and stream)."""
     import threading
@@ -183,6 +195,8 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_thread
             r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t1
             send(("done", r))
 
+    global _FIT_THREADS
+    _FIT_THREADS = max(1, int(fit_threads))
     fitters = [threading.Thread(target=fit_loop, daemon=True) for _ in range(max(1, int(fit_threads)) - 1)]
     for th in fitters:
         th.start()
@@ -300,6 +314,8 @@ class ReplicatePool:
             from concurrent.futures import ThreadPoolExecutor
             n_fit = max(1, min(self.threads, len(units)))
             room = threading.Semaphore(n_fit + 1)
+            global _FIT_THREADS
+            _FIT_THREADS = n_fit
 
             def host(u):
                 room.acquire()
@@ -330,6 +346,7 @@ class ReplicatePool:
                 fits = [ex_fit.submit(fit_one, i, f) for i, f in enumerate(hosts)]
                 for f in fits:
                     f.result()
+            _FIT_THREADS = 1
             tl["run_finished"] = time.time()
             return out
         from collections import deque
