@@ -160,3 +160,67 @@ int loc_blosc1_info(const uint8_t* src, int64_t src_len, int64_t* out) {
     out[0] = rd32(src + 4); out[1] = rd32(src + 8); out[2] = rd32(src + 12); out[3] = src[3]; out[4] = src[2];
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * filter_snps + split transposes on the host (reference: locator.py:265-273, :295-308; scikit-allel's count_alleles /
+ * is_biallelic / to_allele_counts there).  The NumPy spelling of these made the parent's prologue of a --bootstrap run
+ * its serial part (15 s of a 669 s job on one GPU, but a tenth of the wall on eight): boolean temporaries over
+ * 560,000 x 1000 x 2 calls and strided ploidy reads.  One pass per function over the calls; Python drives them over
+ * variant chunks from a few threads (ctypes releases the GIL).  Integer work: bit-identical to the NumPy path.
+ * --------------------------------------------------------------------------------------------------------------- */
+/* keep[v] = 1 iff exactly two distinct alleles 0..127 occur among the n_calls = N * ploidy calls of variant v (negative =
+ * missing, ignored) and (min_mac == 1 or allele 1 occurs at least min_mac times).  Returns the number kept in [v0, v1). */
+int64_t loc_snp_flags(const int8_t* gt, int64_t v0, int64_t v1, int64_t n_calls, int min_mac, uint8_t* keep) {
+    int64_t kept = 0;
+    for (int64_t v = v0; v < v1; ++v) {
+        const int8_t* row = gt + v * n_calls;
+        uint64_t m0 = 0, m1 = 0;
+        int64_t c1 = 0;
+        for (int64_t i = 0; i < n_calls; ++i) {
+            const int a = row[i];
+            if (a >= 0) {
+                if (a < 64) m0 |= (uint64_t)1 << a; else m1 |= (uint64_t)1 << (a - 64);
+                c1 += a == 1;
+            }
+        }
+        const int distinct = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+        const int k = distinct == 2 && (min_mac == 1 || c1 >= min_mac);
+        keep[v] = (uint8_t)k;
+        kept += k;
+    }
+    return kept;
+}
+
+/* ac[pos[v]][s] = number of allele-1 copies of sample s at kept variant v (to_allele_counts()[:, :, 1]), v in [v0, v1);
+ * pos = exclusive prefix sum of keep; ac rows are n_samples bytes. */
+void loc_snp_allele_counts(const int8_t* gt, int64_t v0, int64_t v1, int64_t n_samples, int ploidy, const uint8_t* keep,
+                           const int64_t* pos, int8_t* ac) {
+    for (int64_t v = v0; v < v1; ++v) {
+        if (!keep[v]) continue;
+        const int8_t* row = gt + v * n_samples * ploidy;
+        int8_t* out = ac + pos[v] * n_samples;
+        if (ploidy == 2) {
+            for (int64_t s = 0; s < n_samples; ++s) out[s] = (int8_t)((row[2 * s] == 1) + (row[2 * s + 1] == 1));
+        } else {
+            for (int64_t s = 0; s < n_samples; ++s) {
+                int c = 0;
+                for (int p = 0; p < ploidy; ++p) c += row[s * ploidy + p] == 1;
+                out[s] = (int8_t)c;
+            }
+        }
+    }
+}
+
+/* out[r][k] = ac[k][rows[r]] for k in [k0, k1): the sample-major matrices of split_train_test (`ac[:, rows].T`), 64 SNPs at a
+ * time so that the strided reads of a block stay in L1 and every write run is one cache line.  out pitch = out_pitch bytes. */
+void loc_rows_transposed(const int8_t* ac, int64_t k0, int64_t k1, int64_t n_samples, const int64_t* rows, int64_t n_rows,
+                         int8_t* out, int64_t out_pitch) {
+    for (int64_t kb = k0; kb < k1; kb += 64) {
+        const int64_t ke = kb + 64 < k1 ? kb + 64 : k1;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int8_t* src = ac + rows[r];
+            int8_t* dst = out + r * out_pitch;
+            for (int64_t k = kb; k < ke; ++k) dst[k] = src[k * n_samples];
+        }
+    }
+}

@@ -112,6 +112,14 @@ def _codecs():
         lib.loc_zstd_decompress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
         lib.loc_zstd_compress.restype = C.c_int64
         lib.loc_zstd_compress.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]
+        lib.loc_snp_flags.restype = C.c_int64
+        lib.loc_snp_flags.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        lib.loc_snp_allele_counts.restype = None
+        lib.loc_snp_allele_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        lib.loc_rows_transposed.restype = None
+        lib.loc_rows_transposed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_int64]
         _CODECS = lib
     return _CODECS
 
@@ -538,13 +546,69 @@ def replace_md(gt, rng=np.random):
     return ac
 
 
-def filter_snps(gt, min_mac=2, max_snps=None, impute_missing=False, rng=np.random, verbose=True):
+HOST_THREADS = 8      # threads of the C passes below (they release the GIL)
+
+
+def _chunks(n, parts):
+    step = max(1, -(-n // max(1, parts)))
+    return [(a, min(a + step, n)) for a in range(0, n, step)]
+
+
+def _filter_snps_native(gt, min_mac):
+    """The biallelic + allele-1-count filters and to_allele_counts()[:, :, 1] of filter_snps as two C passes over the calls
+    (csrc/codecs.c: loc_snp_flags, loc_snp_allele_counts), a few threads each: (ac int8 [K][N], keep flags)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _codecs()
+    gt = np.ascontiguousarray(gt, dtype=np.int8)
+    V, N, P = gt.shape
+    keep = np.zeros(V, np.uint8)
+    parts = _chunks(V, HOST_THREADS * 4)
+    with ThreadPoolExecutor(HOST_THREADS) as ex:
+        list(ex.map(lambda ab: lib.loc_snp_flags(gt.ctypes.data, ab[0], ab[1], N * P, int(min_mac), keep.ctypes.data), parts))
+        pos = np.zeros(V, np.int64)
+        np.cumsum(keep[:-1], out=pos[1:]) if V > 1 else None
+        K = int(keep.sum())
+        ac = np.empty((K, N), np.int8)
+        list(ex.map(lambda ab: lib.loc_snp_allele_counts(gt.ctypes.data, ab[0], ab[1], N, P, keep.ctypes.data,
+                                                         pos.ctypes.data, ac.ctypes.data), parts))
+    return ac, keep
+
+
+def rows_transposed(ac, rows):
+    """`ac[:, rows].T` (split_train_test, locator.py:303-306) as a C blocked transpose on a few threads: the sample-major
+    int8 matrix [len(rows)][K] the training path uploads."""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    K, N = ac.shape
+    out = np.empty((len(rows), K), ac.dtype)
+    if len(rows) == 0 or K == 0:
+        return out
+    if ac.dtype.itemsize != 1 or not ac.flags.c_contiguous:
+        return np.ascontiguousarray(ac[:, rows].T)
+    lib = _codecs()
+    step = (max(64, -(-K // (HOST_THREADS * 4))) + 63) // 64 * 64          # 64-SNP blocks: a write run is one cache line
+    parts = [(a, min(a + step, K)) for a in range(0, K, step)]
+    with ThreadPoolExecutor(HOST_THREADS) as ex:
+        list(ex.map(lambda ab: lib.loc_rows_transposed(ac.ctypes.data, ab[0], ab[1], N, rows.ctypes.data, len(rows),
+                                                       out.ctypes.data, K), parts))
+    return out
+
+
+def filter_snps(gt, min_mac=2, max_snps=None, impute_missing=False, rng=np.random, verbose=True, native=True):
     """locator.py:265-281: biallelic sites -> allele-1 count >= min_mac (skipped when min_mac == 1) ->
     allele-1 count matrix (sites x samples) -> optional random subset of max_SNPs sites.
     Quirks kept: the count filtered on is allele 1's, not the minor allele's; monomorphic
-    sites never pass (Q8)."""
+    sites never pass (Q8).  native: the two filters and the allele counts as C passes (same integers; the NumPy spelling
+    below stays as their restatement and as the --impute_missing path, whose draws follow the filtered array)."""
     if verbose:
         print("filtering SNPs")
+    if native and not impute_missing and np.ndim(gt) == 3 and gt.shape[0] > 0 and int(np.min(gt.shape)) > 0:
+        ac, _ = _filter_snps_native(gt, min_mac)
+        if max_snps is not None:
+            ac = ac[rng.choice(range(ac.shape[0]), max_snps, replace=False), :]
+        if verbose:
+            print("running on " + str(len(ac)) + " genotypes after filtering\n\n\n")
+        return ac
     tmp = count_alleles(gt)
     gt = gt[is_biallelic(tmp)]
     if not min_mac == 1:

@@ -163,7 +163,13 @@ def load_genotypes():
     if args.zarr is not None:
         print("reading zarr")
         callset = G.open_group(args.zarr, mode="r")
-        return np.asarray(callset["calldata/GT"][:], dtype=np.int8), np.asarray(callset["samples"][:])
+        za = callset["calldata/GT"]
+        if za.dtype == np.int8 and za.ndim == 3:
+            gt = np.empty(za.shape, np.int8)            # chunks decoded / read on a few threads, straight into place
+            za.read_into(gt, 0, za.shape[0], threads=G.HOST_THREADS)
+        else:
+            gt = np.asarray(za[:], dtype=np.int8)
+        return gt, np.asarray(callset["samples"][:])
     if args.vcf is not None:
         print("reading VCF")
         vcf = G.read_vcf(args.vcf)
@@ -219,7 +225,7 @@ def split_indices(locs, train_split):
 def split_train_test(ac, locs):
     """locator.py:295-308: row sets from split_indices, genotypes as sample-major matrices."""
     train, test, pred = split_indices(locs, args.train_split)
-    rows = lambda idx: ac[:, idx].T if len(idx) else np.zeros((0, ac.shape[0]), ac.dtype)
+    rows = lambda idx: G.rows_transposed(ac, idx) if len(idx) else np.zeros((0, ac.shape[0]), ac.dtype)
     return train, test, rows(train), rows(test), locs[train], locs[test], pred, rows(pred)
 
 
@@ -642,10 +648,8 @@ def _load_window(unit, draw_split=False):
     else:
         ac = G.filter_snps(genotypes, min_mac=unit["args"].min_mac if "args" in unit else args.min_mac, verbose=False)
         train, test, pred, locs = unit["train"], unit["test"], unit["pred"], unit["locs"]
-    unit.update(traingen=np.ascontiguousarray(np.transpose(ac[:, train])),
-                testgen=np.ascontiguousarray(np.transpose(ac[:, test])),
-                predgen=(np.ascontiguousarray(np.transpose(ac[:, pred])) if len(pred)
-                         else np.zeros((0, ac.shape[0]), ac.dtype)),
+    unit.update(traingen=G.rows_transposed(ac, train), testgen=G.rows_transposed(ac, test),
+                predgen=(G.rows_transposed(ac, pred) if len(pred) else np.zeros((0, ac.shape[0]), ac.dtype)),
                 trainlocs=locs[train], testlocs=locs[test], pred=pred)
     return unit
 
@@ -655,7 +659,11 @@ def _bootstrap_units(n_sites):
     reference order (locator.py:635-650).  Units are small: the genotype rows travel once as `shared`."""
     units = [dict(name="boot FULL", replicate=0, boot="FULL", site_order=None, cache_base=True)]
     for boot in range(args.nboots):
-        np.random.seed(np.random.choice(range(int(1e6)), 1))
+        # the reference's `np.random.seed(np.random.choice(range(int(1e6)), 1))` (locator.py:637) without building a
+        # million-element array per replicate: for an int population the legacy generator makes the very same draw
+        # (randint(0, 10^6, 1); value = index) - same seeds, same stream (tests/test_host.py, tests/test_oracle.py known
+        # answers), 80 ms -> 0.1 ms per replicate: 20 s of a 256-replicate parent prologue
+        np.random.seed(np.random.choice(int(1e6), 1))
         site_order = np.random.choice(n_sites, n_sites, replace=True).astype(np.int32)
         units.append(dict(name=f"boot {boot}", replicate=boot + 1, boot=boot, site_order=site_order,
                           cache_base=True))

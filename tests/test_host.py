@@ -720,3 +720,27 @@ def test_fit_threads_in_one_process_and_in_worker_processes():
     assert R.ReplicatePool(_Args(), _quick_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=1, max_workers=1).threads == 1
     p3 = R.ReplicatePool(_Args(), _quick_fit, n_gpus=1, fits_per_gpu=4, procs_per_gpu=2, max_workers=3)
     assert p3.n * p3.threads >= 3 and p3.n <= 2
+
+
+def test_native_host_filter_and_transposes_equal_the_numpy_restatement():
+    """csrc/codecs.c loc_snp_flags / loc_snp_allele_counts / loc_rows_transposed (the parent's prologue of --bootstrap and the
+    eager --windows path) against the NumPy spelling of allel's count_alleles -> is_biallelic -> to_allele_counts()[:, :, 1]
+    (genotypes.filter_snps(native=False)) and `ac[:, rows].T`: missing calls, tri-allelic and monomorphic sites, alleles up
+    to 5, min_mac 1 / 2 / 7, haploid and triploid calls, odd sizes around the 64-SNP blocks of the transpose."""
+    rng = np.random.default_rng(11)
+    for V, N, P in ((1000, 37, 2), (4099, 130, 2), (257, 513, 2), (300, 20, 1), (300, 20, 3), (63, 9, 2), (1, 5, 2)):
+        af = rng.beta(0.3, 0.9, V)
+        af[rng.random(V) < 0.1] = 0.0
+        gt = (rng.random((V, N, P)) < af[:, None, None]).astype(np.int8)
+        gt[rng.random(V) < 0.05, rng.integers(0, N), 0] = rng.integers(2, 6)
+        gt[rng.random((V, N, P)) < 0.02] = -1
+        for mm in (1, 2, 7):
+            ref = G.filter_snps(gt, mm, verbose=False, native=False)
+            got = G.filter_snps(gt, mm, verbose=False, native=True)
+            assert got.dtype == ref.dtype and got.shape == ref.shape and np.array_equal(got, ref), (V, N, P, mm)
+        rows = rng.permutation(N)[: max(1, N - 2)]
+        assert np.array_equal(G.rows_transposed(ref, rows), np.ascontiguousarray(ref[:, rows].T))
+        assert G.rows_transposed(ref, np.zeros(0, np.int64)).shape == (0, ref.shape[0])
+    v = G.read_vcf(VCF)["calldata/GT"]                         # the reference's example: 5,830 SNPs either way
+    assert np.array_equal(G.filter_snps(v, 2, verbose=False), G.filter_snps(v, 2, verbose=False, native=False))
+    assert G.filter_snps(v, 2, verbose=False).shape[0] == 5830
