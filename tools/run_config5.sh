@@ -14,11 +14,5 @@ t2=$(date +%s%N)
 echo "locator --bootstrap --nboots ${NBOOTS:-256}: wall $(( (t2 - t1) / 1000000 )) ms" >> gpurun_out/config5.log
 ls /tmp/c5out | wc -l >> gpurun_out/config5.log
 head -3 /tmp/c5out/boot_bootFULL_predlocs.txt >> gpurun_out/config5.log 2>&1
-python3 - >> gpurun_out/config5.log 2>&1 <<'PY'
-import glob, numpy as np
-ep = []
-for f in sorted(glob.glob("/tmp/c5out/boot_boot*_history.txt")):
-    ep.append(sum(1 for _ in open(f)) - 1)
-print("history files", len(ep), "epochs mean/min/max", np.mean(ep) if ep else None, min(ep) if ep else None, max(ep) if ep else None)
-PY
+echo "predlocs files: $(ls /tmp/c5out | grep -c predlocs)" >> gpurun_out/config5.log
 tail -5 gpurun_out/config5.log
