@@ -2,9 +2,13 @@
 /root/reference/locator/locator.py:330-394; semantics restated in SURVEY.md A.4/A.5).
 
 One epoch = ceil(n_train / batch) minibatch steps (partial last batch kept) + one validation
-sweep in inference mode.  The whole epoch is captured once into a HIP graph and replayed; the
-host only refreshes the permutation, reads back the per-step losses and validation distances,
-and runs the callback state machines.
+sweep in inference mode + the three callbacks, all on the device: `loc_epoch_callbacks` turns the epoch's per-step
+losses and validation distances into loss / val_loss and runs ModelCheckpoint / EarlyStopping / ReduceLROnPlateau on
+a small state struct in HBM, `loc_snapshot_if` copies the parameters when val_loss improved.  The whole epoch is
+captured once into a HIP graph and replayed; the host (`FitLoop`) only draws and uploads the next permutation, fills
+the dropout masks, replays - up to `depth` epochs ahead of the device - and reads one 32-byte history row per epoch
+with a lag.  `Callbacks` below is the host restatement of the same state machines (the tests replay the device's
+decisions through it); `EpochRunner.run_epoch` is the one-epoch-at-a-time form the parity tests drive.
 """
 from __future__ import annotations
 
