@@ -132,6 +132,10 @@ typedef struct loc_net {
                                 loc_stack_dw_adam; refresh with loc_transpose_hidden after loading weights) */
     /* workspace, sized by loc_workspace_floats() */
     float* ws;
+    float* ws_predict;       /* optional second workspace of the same size for loc_predict / loc_predict_scan (NULL = ws).  A fit
+                                that chains the last step of an epoch into the first layer-1 forward of the next leaves that
+                                forward's partial sums and scale / shift in ws across the epoch's validation sweep, which
+                                therefore must work elsewhere */
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
     int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32),
@@ -244,6 +248,14 @@ int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows, i
 int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last, int n_steps,
                        int K, int Kp, const float* gamma, const float* beta, float* mov_mean, float* mov_var,
                        float* stats_ep, float* bn4, void* stream);
+/* The two halves of loc_bn_epoch_stats on their own: the batch statistics of an epoch's minibatches (they depend on X and
+ * the permutation only, so the NEXT epoch's can be computed while this one trains), and the n_steps moving-statistics
+ * updates of an epoch (+ step 0's [scale|shift|mean|rstd] into bn4 unless bn4 is NULL: an epoch whose first layer-1
+ * forward was chained into the previous epoch's last step finds them there already). */
+int loc_bn_epoch_stats_only(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last, int n_steps,
+                            int K, int Kp, float* stats_ep, void* stream);
+int loc_bn_epoch_finish(int n_steps, int K, int Kp, const float* gamma, const float* beta, float* mov_mean, float* mov_var,
+                        const float* stats_ep, float* bn4, void* stream);
 /* Inference: scale/shift from the moving statistics. */
 int loc_bn_infer_scale_shift(int K, int Kp, const float* gamma, const float* beta, const float* mov_mean,
                              const float* mov_var, float* out4, void* stream);

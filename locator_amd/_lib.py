@@ -46,7 +46,7 @@ class Tuning(C.Structure):
 class Net(C.Structure):
     _fields_ = [("d", Dims), ("params", vp), ("adam_m", vp), ("adam_v", vp), ("alpha_tab", vp),
                 ("alpha_tab_len", C.c_int), ("lr", vp), ("t_base", vp), ("X", vp), ("x_pitch", C.c_int64),
-                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
+                ("Y", vp), ("drop_p", C.c_float), ("wht", vp), ("ws", vp), ("ws_predict", vp), ("l1_fwd_grid", C.c_int), ("l1_bwd_grid", C.c_int),
                 ("slot_rows", C.c_int), ("predict_pieces", C.c_int), ("l1_image", vp), ("l1_image_bytes", C.c_int64), ("x_max", C.c_int), ("predict_digits", C.c_int),
                 ("l1_image_ready", C.c_int), ("X2", vp), ("x2_pitch", C.c_int64), ("l1_scan_ready", C.c_int), ("tune", Tuning)]
 
@@ -114,6 +114,8 @@ SIGNATURES = {
                                        vp, C.POINTER(Tuning), vp]),
     "loc_bn_epoch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                      vp, vp, vp]),
+    "loc_bn_epoch_stats_only": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "loc_bn_epoch_finish": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "loc_workspace_bn4": (vp, [C.POINTER(Net)]),
     "loc_event_create_notiming": (C.c_int, [C.POINTER(vp)]),
     "loc_dense_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, vp]),

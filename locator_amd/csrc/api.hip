@@ -334,7 +334,7 @@ extern "C" int loc_predict_scan(const loc_net* net, void* stream) {
     loc_layout lay;
     loc_param_layout(d, &lay);
     const float* P = net->params;
-    ws_view w = carve(d, net->ws, 0, LOC_ROWS, slot_cap_of(net));
+    ws_view w = carve(d, net->ws_predict ? net->ws_predict : net->ws, 0, LOC_ROWS, slot_cap_of(net));
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var, w.bn4, stream));
     return loc_l1_quant_scan(d, w.bn4, P + lay.w1, net->l1_image, stream);
 }
@@ -346,7 +346,7 @@ extern "C" int loc_predict(const loc_net* net, const int32_t* rows, int n, float
     loc_layout lay;
     loc_param_layout(d, &lay);
     const float* P = net->params;
-    ws_view w = carve(d, net->ws, 0, LOC_ROWS, slot_cap_of(net));
+    ws_view w = carve(d, net->ws_predict ? net->ws_predict : net->ws, 0, LOC_ROWS, slot_cap_of(net));
     const int Hp = d->Hp, L = d->L;
     const int64_t blk = 32 * (int64_t)Hp, HH = (int64_t)Hp * Hp;
     TRY(loc_bn_infer_scale_shift(d->K, d->Kp, P + lay.gamma, P + lay.beta, P + lay.mov_mean, P + lay.mov_var,

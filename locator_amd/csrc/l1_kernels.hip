@@ -119,6 +119,7 @@ __global__ void bn_epoch_finish_kernel(int K, int Kp, int n_steps, const float* 
         scale = gamma[k] * rstd0;
         shift = beta[k] - mean0 * scale;
     }
+    if (bn4 == nullptr) return;            // moving statistics only (step 0's scale / shift came with a chained forward)
     bn4[k] = scale;
     bn4[Kp + k] = shift;
     bn4[2 * (int64_t)Kp + k] = mean0;
@@ -925,6 +926,29 @@ extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32
     hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
                        X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
     LOC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_epoch_finish_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, Kp,
+                       n_steps, stats_ep, gamma, beta, mov_mean, mov_var, bn4);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+
+// The two halves on their own (round 4: an epoch whose first layer-1 forward was chained into the previous epoch's last
+// step computes the NEXT epoch's batch statistics early and applies its own moving-statistics updates without touching
+// the scale / shift the chained kernel left): stats only, then the n_steps moving updates (+ step 0's bn4 unless NULL).
+extern "C" int loc_bn_epoch_stats_only(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last,
+                                       int n_steps, int K, int Kp, float* stats_ep, void* stream) {
+    if (batch < 1 || batch > LOC_BIG_BATCH_MAX || n_last < 1 || n_last > batch || n_steps < 1) {
+        loc_set_error("loc_bn_epoch_stats_only: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
+        return -1;
+    }
+    hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
+                       X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int loc_bn_epoch_finish(int n_steps, int K, int Kp, const float* gamma, const float* beta, float* mov_mean,
+                                   float* mov_var, const float* stats_ep, float* bn4, void* stream) {
+    if (n_steps < 1) { loc_set_error("loc_bn_epoch_finish: n_steps=%d", n_steps); return -1; }
     hipLaunchKernelGGL(bn_epoch_finish_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, Kp,
                        n_steps, stats_ep, gamma, beta, mov_mean, mov_var, bn4);
     LOC_CHECK_LAUNCH();

@@ -100,6 +100,7 @@ class LocatorNet:
         self.lr_t = torch.full((1,), 1e-3, dtype=torch.float32, device=dev)
         self.t_base_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ws = torch.empty(self.lib.loc_workspace_floats(C.byref(self.d)), dtype=torch.float32, device=dev)
+        self.ws_predict = None             # second workspace for predicts (train.EpochRunner(xchain=True) allocates it)
         # transposed hidden kernels for the fused backward chain (derived state, see refresh_transposed)
         # --nlayers 1 has no hidden stack (and its Dropout acts on the BatchNorm output): per-layer kernels
         self.use_fused = bool(self.lib.loc_stack_fused_supported(self.d.Hp)) and self.d.L >= 2
@@ -150,6 +151,8 @@ class LocatorNet:
             need = self.lib.loc_workspace_floats_batch(C.byref(self.d), int(batch_size))
             if self.ws.numel() < need:
                 self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+                if self.ws_predict is not None:
+                    self.ws_predict = torch.empty_like(self.ws)
         else:
             self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
         self._net = None
@@ -166,6 +169,7 @@ class LocatorNet:
         n.drop_p = self.drop_p
         n.wht = self.wht.data_ptr() if self.wht is not None else None
         n.ws = self.ws.data_ptr()
+        n.ws_predict = self.ws_predict.data_ptr() if self.ws_predict is not None else None
         n.l1_fwd_grid, n.l1_bwd_grid = self.l1_fwd_grid, self.l1_bwd_grid
         n.slot_rows = self.slot_rows
         n.predict_pieces = self.predict_pieces
@@ -334,6 +338,20 @@ class LocatorNet:
                                                P + 4 * lay.beta, P + 4 * lay.mov_mean, P + 4 * lay.mov_var,
                                                _ptr(stats_ep), self.lib.loc_workspace_bn4(C.byref(net)), _stream()),
                    "loc_bn_epoch_stats")
+
+    def epoch_bn_stats_only(self, rows_all, batch, n_last, n_steps, stats_ep):
+        """Only the batch statistics of an epoch's minibatches (loc_bn_epoch_stats_only): nothing of the model changes."""
+        d = self.d
+        _lib.check(self.lib.loc_bn_epoch_stats_only(self.X.data_ptr(), self.X.stride(0), _ptr(rows_all), int(batch), int(n_last),
+                                                    int(n_steps), d.K, d.Kp, _ptr(stats_ep), _stream()), "loc_bn_epoch_stats_only")
+
+    def epoch_bn_finish(self, n_steps, stats_ep):
+        """Only the epoch's moving-statistics updates (loc_bn_epoch_finish with bn4 = NULL)."""
+        self.params_changed()
+        d, lay, P = self.d, self.lay, self.params.data_ptr()
+        _lib.check(self.lib.loc_bn_epoch_finish(int(n_steps), d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta,
+                                                P + 4 * lay.mov_mean, P + 4 * lay.mov_var, _ptr(stats_ep), None, _stream()),
+                   "loc_bn_epoch_finish")
 
     def predict_rows(self, rows, n, yhat, dist=None):
         """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""

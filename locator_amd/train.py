@@ -73,9 +73,14 @@ class History:
 class EpochRunner:
     """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
 
-    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True, chain=None):
+    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True, chain=None, xchain=False):
         """chain: None = chain consecutive steps where the library supports it (LocatorNet.chain_supported), False =
-        one layer-1 forward launch per step (the unchained schedule; tests compare the two)."""
+        one layer-1 forward launch per step (the unchained schedule; tests compare the two).
+        xchain: chain ACROSS the epoch boundary as well (needs chained steps and start_epoch(perm, perm_next=...)): the last
+        step of epoch e also computes the layer-1 forward of epoch e + 1's first minibatch, whose rows and batch statistics
+        are known an epoch early (they depend on X and the next permutation only).  The unchained first forward of every
+        epoch but the first disappears; the validation sweep, which sits between the two steps, works in a second workspace
+        (loc_net.ws_predict) so that the hand-over survives it."""
         self.slot_rows = net.set_batch(int(batch_size))      # validates 1..128 and the shape constraints
         self.net = net
         dev = net.device
@@ -105,6 +110,18 @@ class EpochRunner:
         self.step_sizes = np.array([min(self.batch, self.n_train - j * self.batch) for j in range(self.steps)])
         net.cnet()
         self.chain = net.chain_supported() if chain is None else (bool(chain) and net.chain_supported())
+        self.xchain = bool(xchain) and self.chain
+        if self.xchain:
+            # permutation and batch statistics exist twice, by epoch parity: epoch e trains from [e % 2] while [1 - e % 2]
+            # receives epoch e + 1's; the captured graph differs by parity, so there are two of them
+            self.perm_dev2 = [self.perm_dev, torch.zeros_like(self.perm_dev)]
+            self.stats_ep2 = [self.stats_ep, torch.zeros_like(self.stats_ep)]
+            self.graphs = [None, None]
+            if len(self.perm_ring) < 3:       # two uploads at the first epoch, one per epoch after: never reuse a pending buffer
+                self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory() for _ in range(3)]
+            if getattr(net, "ws_predict", None) is None:
+                net.ws_predict = torch.empty_like(net.ws)
+            net.cnet()
 
     def enable_device_callbacks(self, patience, lr0, lr_patience, lr_factor, max_epochs, depth=2):
         """ModelCheckpoint / EarlyStopping / ReduceLROnPlateau evaluated on the device at the end of every epoch
@@ -129,7 +146,7 @@ class EpochRunner:
         if net.best is None:
             net.best = torch.empty_like(net.params)
         net.lr_t.fill_(st.lr)
-        self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory() for _ in range(int(depth) + 2)]
+        self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory() for _ in range(int(depth) + 3)]
         self.perm_host = self.perm_ring[0]
 
     def read_cb_state(self):
@@ -138,24 +155,42 @@ class EpochRunner:
         raw = self.cb["state"].cpu().numpy().tobytes()
         return _lib.CbState.from_buffer_copy(raw)
 
-    def enqueue(self, ev=None):
+    def enqueue(self, ev=None, epoch=0):
         net = self.net
         sz = 2 * net.d.Kp
-        net.epoch_bn_stats(self.perm_dev, self.batch, int(self.step_sizes[-1]), self.steps, self.stats_ep)
+        n_last = int(self.step_sizes[-1])
+        if self.xchain:
+            p = epoch & 1
+            perm_dev, stats_ep = self.perm_dev2[p], self.stats_ep2[p]
+            perm_nx, stats_nx = self.perm_dev2[1 - p], self.stats_ep2[1 - p]
+            if epoch == 0:
+                net.epoch_bn_stats(perm_dev, self.batch, n_last, self.steps, stats_ep)       # statistics, moving updates, step 0's bn4
+            else:
+                net.epoch_bn_finish(self.steps, stats_ep)                                      # moving updates only: bn4 is the hand-over
+            net.epoch_bn_stats_only(perm_nx, self.batch, n_last, self.steps, stats_nx)        # the NEXT epoch's, an epoch early
+        else:
+            perm_dev, stats_ep = self.perm_dev, self.stats_ep
+            net.epoch_bn_stats(perm_dev, self.batch, n_last, self.steps, stats_ep)
         for j in range(self.steps):
             nb = int(self.step_sizes[j])
             mask = self.masks[j * self.mask_stride:] if self.masks is not None else None
             e0, e1 = (ev[j] if ev is not None else (None, None))
-            nxt = self.stats_ep[(j + 1) * sz:] if j + 1 < self.steps else None
+            nxt = stats_ep[(j + 1) * sz:] if j + 1 < self.steps else None
             if self.chain:
                 # the epoch's minibatches are all known: step j's layer-1 backward also computes step j + 1's layer-1
                 # forward from the updated weights while they are in registers (one pass over W1 per step)
                 last = j + 1 >= self.steps
-                net.train_step_chain(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], nxt,
-                                     None if last else self.perm_dev[(j + 1) * self.batch:],
-                                     0 if last else int(self.step_sizes[j + 1]), j > 0, e0, e1)
+                rows_next = None if last else perm_dev[(j + 1) * self.batch:]
+                nb_next = 0 if last else int(self.step_sizes[j + 1])
+                fwd_done = j > 0
+                if self.xchain:
+                    if last:                     # ... and the epoch's last step computes the next epoch's first forward
+                        rows_next, nb_next, nxt = perm_nx, int(self.step_sizes[0]), stats_nx
+                    fwd_done = j > 0 or epoch > 0
+                net.train_step_chain(perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], nxt, rows_next, nb_next,
+                                     fwd_done, e0, e1)
                 continue
-            net.train_step(self.perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
+            net.train_step(perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
                            bn_ready=True, bn_next=nxt)
         if self.n_val:
             net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
@@ -170,24 +205,40 @@ class EpochRunner:
                                                _stream()), "loc_snapshot_if")
         net.t_base_t.add_(self.steps)
 
-    def start_epoch(self, perm, ev=None):
-        """Enqueue one epoch on the CURRENT stream and return without waiting (several fits on their own streams can
-        be in flight at once, replicates.py / bench.py --replicates-per-gpu).  perm: permutation of range(n_train)
-        (Keras shuffle=True draws it unseeded; here it is an input)."""
-        net = self.net
-        net.params_changed()                 # a graph replay trains without passing through net.train_step
+    def _upload_perm(self, perm, dst, slot):
         rows = self.train_rows[np.asarray(perm)]
         # pinned staging buffers rotate: with epochs enqueued ahead of the device the copy of epoch e is still pending
         # when the host prepares epoch e + 1 (the ring is depth + 2 long and FitLoop waits for epoch e - depth first)
-        self.perm_host = self.perm_ring[self.epochs_started % len(self.perm_ring)]
-        self.perm_host[:self.n_train] = torch.from_numpy(rows)
-        self.perm_host[self.n_train:] = 0
-        self.perm_dev.copy_(self.perm_host, non_blocking=True)
+        host = self.perm_ring[slot % len(self.perm_ring)]
+        host[:self.n_train] = torch.from_numpy(rows)
+        host[self.n_train:] = 0
+        dst.copy_(host, non_blocking=True)
+        self.perm_host = host
+
+    def start_epoch(self, perm, ev=None, perm_next=None):
+        """Enqueue one epoch on the CURRENT stream and return without waiting (several fits on their own streams can
+        be in flight at once, replicates.py / bench.py --replicates-per-gpu).  perm: permutation of range(n_train)
+        (Keras shuffle=True draws it unseeded; here it is an input).  perm_next (xchain): the NEXT epoch's permutation
+        (None = there is none: the chained forward for it is computed from this epoch's and never used)."""
+        net = self.net
+        net.params_changed()                 # a graph replay trains without passing through net.train_step
+        e = self.epochs_started
+        if self.xchain:
+            p = e & 1
+            if e == 0:
+                self._upload_perm(perm, self.perm_dev2[0], 0)
+            self._upload_perm(perm if perm_next is None else perm_next, self.perm_dev2[1 - p], e + 1)
+        else:
+            self._upload_perm(perm, self.perm_dev, e)
         if self.masks is not None:
-            net.fill_dropout_masks(self.masks, self.masks.numel(), self.epochs_started * self.masks.numel())
+            net.fill_dropout_masks(self.masks, self.masks.numel(), e * self.masks.numel())
         self.epochs_started += 1
         if self.use_graph and ev is None:
-            if self.graph is None and self.epochs_started >= 2:   # epoch 0 ran eagerly = warm-up
+            # epoch 0 runs eagerly = warm-up (with xchain it also differs from the others: it has no hand-over to start
+            # from); with xchain so does epoch 1, and the two parities get a graph each
+            slot = (e & 1) if self.xchain else 0
+            graphs = self.graphs if self.xchain else [self.graph]
+            if graphs[slot] is None and e >= (2 if self.xchain else 1):
                 g = torch.cuda.CUDAGraph()
                 cur = torch.cuda.current_stream()
                 # capture is not allowed on the default stream: torch then captures on a side stream of its own
@@ -195,14 +246,16 @@ class EpochRunner:
                 # thread-local capture mode: another fit of this process (its own thread and stream, replicates.py) keeps
                 # allocating, synchronising and launching while this one captures
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
-                    self.enqueue()
-                self.graph = g
-            if self.graph is not None:
-                self.graph.replay()
+                    self.enqueue(epoch=e)
+                graphs[slot] = g
+                if not self.xchain:
+                    self.graph = g
+            if graphs[slot] is not None:
+                graphs[slot].replay()
             else:
-                self.enqueue()
+                self.enqueue(epoch=e)
         else:
-            self.enqueue(ev)
+            self.enqueue(ev, epoch=e)
         self.stats_host.copy_(self.stats, non_blocking=True)
         self._stream = torch.cuda.current_stream()
 
@@ -231,11 +284,12 @@ class FitLoop:
     `depth` epochs enqueued behind the stop epoch, which change nothing that is kept (frozen state, include/locator_hip.h)."""
 
     def __init__(self, net, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
-                 lr_factor=0.5, perm_fn=None, use_graph=True, chain=None, depth=2, verbose=0, log=print):
+                 lr_factor=0.5, perm_fn=None, use_graph=True, chain=None, depth=2, verbose=0, log=print, xchain=True):
         if len(val_rows) == 0:
             raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
         self.net = net
-        self.runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain)
+        self.runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain, xchain=xchain)
+        self._perms = {}            # permutations drawn ahead (cross-epoch chaining needs epoch e + 1's when e is enqueued)
         self.max_epochs, self.depth = int(max_epochs), max(0, int(depth))
         self.runner.enable_device_callbacks(patience, 1e-3, lr_patience, lr_factor, self.max_epochs, self.depth)
         rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([net.seed, net.replicate, 0x7065726D])))
@@ -256,7 +310,11 @@ class FitLoop:
         if self.stop_epoch is not None or self.submitted >= self.max_epochs:
             return False
         e, cb = self.submitted, self.runner.cb
-        self.runner.start_epoch(self.perm_fn(e), ev)
+        perm = self._perms.pop(e) if e in self._perms else self.perm_fn(e)       # every epoch's drawn once, in epoch order
+        perm_next = None
+        if self.runner.xchain and e + 1 < self.max_epochs:
+            perm_next = self._perms[e + 1] = self.perm_fn(e + 1)
+        self.runner.start_epoch(perm, ev, perm_next)
         cb["hist_host"][e].copy_(cb["hist"][e], non_blocking=True)
         cb["events"][e % len(cb["events"])].record(torch.cuda.current_stream())
         self.submitted += 1
@@ -321,12 +379,12 @@ class FitLoop:
 
 
 def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
-        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print, chain=None, pipelined=True, depth=2):
+        lr_factor=0.5, perm_fn=None, use_graph=True, verbose=0, log=print, chain=None, pipelined=True, depth=2, xchain=True):
     """train_network (locator.py:365-394): fit with checkpoint / early-stop / LR-plateau callbacks, then
     reload the best weights.  Returns a History.  lr_patience None = int(patience / 6) (locator.py:354).
     pipelined: the host enqueues epochs `depth` ahead of the device (False = wait for every epoch before enqueueing the
     next; same kernels, same decisions - they are taken on the device either way - same results bit for bit)."""
     loop = FitLoop(net, train_rows, val_rows, batch_size=batch_size, max_epochs=max_epochs, patience=patience,
                    lr_patience=lr_patience, lr_factor=lr_factor, perm_fn=perm_fn, use_graph=use_graph, chain=chain,
-                   depth=depth if pipelined else 0, verbose=verbose, log=log)
+                   depth=depth if pipelined else 0, verbose=verbose, log=log, xchain=xchain)
     return loop.run()

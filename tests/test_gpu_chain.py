@@ -319,3 +319,36 @@ def test_hand_counted_wait_of_the_chained_kernel_equals_its_drained_build_bit_fo
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert out[0] == out[1], out
+
+
+def _run_xchain(x, y, p, tr, va, perms, xchain, use_graph, width_seed=5):
+    """Epochs through EpochRunner with (or without) the cross-epoch hand-over: epoch e is given epoch e + 1's permutation."""
+    from locator_amd.train import EpochRunner
+    net = build_net(x, y, p, drop_p=0.25, seed=width_seed)
+    runner = EpochRunner(net, tr, va, 32, use_graph=use_graph, chain=True, xchain=xchain)
+    assert runner.xchain == xchain
+    hist = []
+    for e, perm in enumerate(perms):
+        runner.start_epoch(perm, None, perms[e + 1] if xchain and e + 1 < len(perms) else None)
+        hist.append(runner.finish_epoch())
+    _sync()
+    m, v = net.export_adam()
+    return net, hist, net.export_params(), m, v
+
+
+@pytest.mark.parametrize("width,K,n_train", [(256, 40010, 96), (256, 5000, 74), (128, 20000, 96), (64, 9000, 70)])
+def test_cross_epoch_chaining_equals_the_per_epoch_schedule(width, K, n_train):
+    """Round 4: the last step of an epoch also computes the first layer-1 forward of the next epoch (its rows and batch
+    statistics are known an epoch early), so every epoch but the first starts from a hand-over instead of an unchained
+    forward; the validation sweep in between works in a second workspace.  Five epochs (eager, eager, then one captured
+    graph per epoch parity and a replay of each) against the per-epoch chained schedule: same bars as chained against
+    unchained (two fp32 evaluations of the same steps); graph replay against eager enqueue: bit-identical."""
+    x, y, p, rng = make_problem(n_train + 20, K, width, 4, seed=K % 89)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
+    perms = [np.random.default_rng(17 + e).permutation(n_train) for e in range(5)]
+    _, h0, p0, m0, v0 = _run_xchain(x, y, p, tr, va, perms, False, True)
+    _, h1, p1, m1, v1 = _run_xchain(x, y, p, tr, va, perms, True, True)
+    assert maxerr(h0, h1) < 5e-5, (h0, h1)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
+    _, h2, p2, m2, v2 = _run_xchain(x, y, p, tr, va, perms, True, False)
+    assert h1 == h2 and max(params_err(p1, p2).values()) == 0.0
