@@ -401,6 +401,10 @@ def main():
     ap.add_argument("--no-l1-gemm", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
+    ap.add_argument("--side-stats", action="store_true",
+                    help="measurement switch: the next epoch's BN batch statistics on a side stream (FitLoop side_stats)")
+    ap.add_argument("--no-xchain", action="store_true",
+                    help="measurement switch: do not chain the last step of an epoch into the next epoch's first layer-1 forward")
     ap.add_argument("--sync-epochs", action="store_true",
                     help="measurement switch: wait for every epoch before enqueueing the next (FitLoop depth 0) instead of "
                          "running two epochs ahead of the device")
@@ -478,7 +482,7 @@ def main():
             self.rng = np.random.default_rng(99 + replicate)
             self.loop = FitLoop(self.net, train, test, batch_size=args.batch, max_epochs=args.steps + max(args.warmup, 2) + 64, patience=10 ** 6,
                                 lr_patience=16, use_graph=not args.no_graph, chain=False if args.no_chain else None,
-                                perm_fn=lambda e: self.rng.permutation(len(train)), depth=0 if args.sync_epochs else 2)
+                                perm_fn=lambda e: self.rng.permutation(len(train)), depth=0 if args.sync_epochs else 2, xchain=not args.no_xchain, side_stats=args.side_stats)
             self.runner = self.loop.runner
             self.stream = torch.cuda.Stream(device=dev) if R > 1 else torch.cuda.current_stream()
 

@@ -73,7 +73,8 @@ class History:
 class EpochRunner:
     """Enqueues (and optionally graph-captures) one epoch on a LocatorNet."""
 
-    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True, chain=None, xchain=False):
+    def __init__(self, net: LocatorNet, train_rows, val_rows, batch_size=32, use_graph=True, chain=None, xchain=False,
+                 side_stats=False):
         """chain: None = chain consecutive steps where the library supports it (LocatorNet.chain_supported), False =
         one layer-1 forward launch per step (the unchained schedule; tests compare the two).
         xchain: chain ACROSS the epoch boundary as well (needs chained steps and start_epoch(perm, perm_next=...)): the last
@@ -117,6 +118,8 @@ class EpochRunner:
             self.perm_dev2 = [self.perm_dev, torch.zeros_like(self.perm_dev)]
             self.stats_ep2 = [self.stats_ep, torch.zeros_like(self.stats_ep)]
             self.graphs = [None, None]
+            self.side_stats = bool(side_stats)
+            self._side = None
             if len(self.perm_ring) < 3:       # two uploads at the first epoch, one per epoch after: never reuse a pending buffer
                 self.perm_ring = [torch.empty(self.steps * self.batch, dtype=torch.int32).pin_memory() for _ in range(3)]
             if getattr(net, "ws_predict", None) is None:
@@ -167,7 +170,18 @@ class EpochRunner:
                 net.epoch_bn_stats(perm_dev, self.batch, n_last, self.steps, stats_ep)       # statistics, moving updates, step 0's bn4
             else:
                 net.epoch_bn_finish(self.steps, stats_ep)                                      # moving updates only: bn4 is the hand-over
-            net.epoch_bn_stats_only(perm_nx, self.batch, n_last, self.steps, stats_nx)        # the NEXT epoch's, an epoch early
+            # the NEXT epoch's batch statistics, an epoch early - on a side stream (forked here, joined before the epoch's last
+            # step, which is the first to need them): 22 us of streaming that the device can run beside the first steps'
+            # hidden-stack phases, which keep 16 of 256 compute units busy
+            if self.side_stats:
+                cur = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=net.device)
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    net.epoch_bn_stats_only(perm_nx, self.batch, n_last, self.steps, stats_nx)
+            else:
+                net.epoch_bn_stats_only(perm_nx, self.batch, n_last, self.steps, stats_nx)
         else:
             perm_dev, stats_ep = self.perm_dev, self.stats_ep
             net.epoch_bn_stats(perm_dev, self.batch, n_last, self.steps, stats_ep)
@@ -186,6 +200,8 @@ class EpochRunner:
                 if self.xchain:
                     if last:                     # ... and the epoch's last step computes the next epoch's first forward
                         rows_next, nb_next, nxt = perm_nx, int(self.step_sizes[0]), stats_nx
+                        if self.side_stats:
+                            torch.cuda.current_stream().wait_stream(self._side)
                     fwd_done = j > 0 or epoch > 0
                 net.train_step_chain(perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], nxt, rows_next, nb_next,
                                      fwd_done, e0, e1)
@@ -284,11 +300,13 @@ class FitLoop:
     `depth` epochs enqueued behind the stop epoch, which change nothing that is kept (frozen state, include/locator_hip.h)."""
 
     def __init__(self, net, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,
-                 lr_factor=0.5, perm_fn=None, use_graph=True, chain=None, depth=2, verbose=0, log=print, xchain=True):
+                 lr_factor=0.5, perm_fn=None, use_graph=True, chain=None, depth=2, verbose=0, log=print, xchain=True,
+                 side_stats=False):
         if len(val_rows) == 0:
             raise ValueError("fit needs validation rows: checkpoint, early stopping and the LR plateau all monitor val_loss")
         self.net = net
-        self.runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain, xchain=xchain)
+        self.runner = EpochRunner(net, train_rows, val_rows, batch_size, use_graph, chain=chain, xchain=xchain,
+                                  side_stats=side_stats)
         self._perms = {}            # permutations drawn ahead (cross-epoch chaining needs epoch e + 1's when e is enqueued)
         self.max_epochs, self.depth = int(max_epochs), max(0, int(depth))
         self.runner.enable_device_callbacks(patience, 1e-3, lr_patience, lr_factor, self.max_epochs, self.depth)
