@@ -470,10 +470,12 @@ int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, 
  * loc_train_step, mandatory with rows_next).  rows_next NULL = last step of the epoch.  Results equal loc_train_step's
  * up to the summation order of the BatchNorm gamma / beta gradient and of the layer-1 partial sums.
  * loc_train_chain_supported: width padding to 64, 128 or 256, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output.
- * CONTRACT: a step with fwd_done != 0 must directly follow, on the same stream, a chained step whose rows_next /
- * n_b_next / bn_next_stats described it -- the hand-over lives in the workspace (layer-1 partial sums, scale/shift), so
- * nothing that uses net->ws (loc_predict, loc_train_step, loc_bn_epoch_stats) may run in between.  The library cannot
- * check this. */
+ * CONTRACT: a step with fwd_done != 0 must follow, on the same stream, a chained step whose rows_next / n_b_next /
+ * bn_next_stats described it -- the hand-over lives in the workspace (layer-1 partial sums, scale/shift), so nothing that
+ * uses net->ws (loc_train_step, loc_bn_epoch_stats, loc_predict without net->ws_predict) may run in between.  The library
+ * cannot check this.  What MAY run in between: loc_predict / loc_predict_scan when net->ws_predict gives them their own
+ * workspace, loc_bn_epoch_stats_only, loc_bn_epoch_finish with bn4 = NULL, the callback kernels -- which is how the last
+ * step of an epoch chains into the first step of the next across the validation sweep (locator_amd/train.py, xchain). */
 int loc_train_chain_supported(const loc_net* net);
 int loc_train_step_chain(const loc_net* net, const int32_t* rows, int n_b, int t_off, const uint8_t* mask,
                          float* loss_out, const float* bn_next_stats, const int32_t* rows_next, int n_b_next,

@@ -261,8 +261,20 @@ class EpochRunner:
                 kw = {} if cur == torch.cuda.default_stream() else {"stream": cur}
                 # thread-local capture mode: another fit of this process (its own thread and stream, replicates.py) keeps
                 # allocating, synchronising and launching while this one captures
-                with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
-                    self.enqueue(epoch=e)
+                # ... and no cyclic garbage collection while the capture is open: a collection pass triggered by the ~100
+                # small allocations of enqueue() may run the destructor of some unreachable torch object (an older fit's
+                # graph, an event), whose HIP call is illegal inside a capture and aborts the process - seen once in a few
+                # runs of the GPU suite (`Fatal Python error: Aborted ... Garbage-collecting`).  torch.cuda.graph() itself
+                # collects everything collectable before the capture begins.
+                import gc
+                gc_was = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
+                        self.enqueue(epoch=e)
+                finally:
+                    if gc_was:
+                        gc.enable()
                 graphs[slot] = g
                 if not self.xchain:
                     self.graph = g
