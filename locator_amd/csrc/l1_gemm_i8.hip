@@ -107,21 +107,26 @@ __global__ __launch_bounds__(G8_HP) void l1_colmax_kernel(const float* __restric
 __global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
                                                               const float* __restrict__ sumabs_part, int nparts, int K, int H,
                                                               float* __restrict__ guard) {
-    __shared__ float R[G8_HP];
+    __shared__ __attribute__((aligned(16))) float R[G8_HP];
     __shared__ float qs[4][G8_HP];
-    // 1024 threads: thread (q, n) adds the workgroup shares b = q, q + 4, ... of unit n with eight loads in flight (a single
-    // wave per unit walking 512 strided shares one after the other took 127 us); the four quarters, then the units'
-    // statistics, are combined in a fixed order
+    // 1024 threads: thread (q, n) adds the workgroup shares b = q, q + 4, ... of unit n, all at once (a single
+    // wave per unit walking 512 strided shares one after the other took 127 us); the four
+    // quarters, then the units' statistics, are combined in a fixed order
     {
         const int n = threadIdx.x & (G8_HP - 1), q = threadIdx.x >> 8;
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int b = q;
-        for (; b + 28 < nparts; b += 32) {
+        // the shares were written by workgroups on every XCD, so each load is a trip to memory: all of a thread's loads
+        // (nparts <= 256: at most 64) are issued at once, then added in a fixed order
+        float a[64];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += sumabs_part[(int64_t)(b + 4 * e) * G8_HP + n];
+        for (int e = 0; e < 64; ++e) {
+            const int b = q + 4 * e;
+            a[e] = b < nparts ? sumabs_part[(int64_t)b * G8_HP + n] : 0.f;
         }
-        for (int e = 0; b < nparts; b += 4, ++e) a[e & 7] += sumabs_part[(int64_t)b * G8_HP + n];
-        qs[q][n] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+        for (int w2 = 32; w2 > 0; w2 >>= 1)
+#pragma unroll
+            for (int e = 0; e < w2; ++e) a[e] += a[e + w2];
+        qs[q][n] = a[0];
     }
     __syncthreads();
     // (every thread reaches the barriers below; the statistics are the first 256 threads' work)
@@ -134,8 +139,23 @@ __global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __
     if (first) R[n] = r;
     __syncthreads();
     // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
+    // (sixteen values per round of LDS reads: one value per read, one read at a time, was most of this kernel's 16 us)
     int rank = 0;
-    for (int j = 0; j < H; ++j) rank += (R[j] < r || (R[j] == r && j < n)) ? 1 : 0;
+    if (first) {               // 256 x 256 comparisons: by the four waves that need them, not by all sixteen
+        const f32x4* R4 = reinterpret_cast<const f32x4*>(R);
+#pragma unroll 1
+        for (int j0 = 0; j0 < G8_HP; j0 += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = R4[j0 / 4 + e];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = v[e >> 2][e & 3];
+                const int j = j0 + e;
+                rank += (j < H && (x < r || (x == r && j < n))) ? 1 : 0;
+            }
+        }
+    }
     __shared__ float red[G8_HP];
     if (first) red[n] = r;
     __syncthreads();
@@ -630,7 +650,7 @@ extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, co
     uint32_t* colmax = reinterpret_cast<uint32_t*>(base + g8_colmax_off());
     float* guard = reinterpret_cast<float*>(base + g8_guard_off());
     float* cpart = reinterpret_cast<float*>(base + g8_cpart_off());
-    const int nkt = g8_nkt64(d), grid = nkt < 512 ? nkt : 512;
+    const int nkt = g8_nkt64(d), grid = nkt < 256 ? nkt : 256;           // one workgroup per compute unit: 256 shares for the guard
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
     if (e != hipSuccess) { loc_set_error("loc_l1_quant_scan: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
