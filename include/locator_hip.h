@@ -371,7 +371,7 @@ int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* 
  * bn_next_stats = [mean|var] of the next minibatch), and -- rows_next non-NULL -- partial[g][32][256] of the next
  * minibatch's layer-1 pre-activations from the updated weights, g < min(grid, ceil(Kp/32 / s)) workgroups x s =
  * loc_l1_chain_groups_per_workgroup(Hp) groups each (partial[g * s + slot][32][Hp]), for the reduction of loc_l1_forward.  rows_next NULL: backward only (last step of an epoch). */
-int loc_l1_chain_supported(int Hp);            /* padded width 256, 128 or 64 */
+int loc_l1_chain_supported(int Hp);            /* padded width 512, 256, 128 or 64 */
 int loc_l1_chain_groups_per_workgroup(int Hp); /* k-tiles a workgroup owns at a time = partial groups it leaves: 1, 2, 4 */
 int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b, const int32_t* rows_next,
                                int n_b_next, const loc_dims* d, float* bn4, const float* bn_next_stats, const float* dz1,
@@ -469,7 +469,7 @@ int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, 
  * of running the layer-1 forward.  The epoch-level BN statistics are required (bn_ready is implied; bn_next_stats as in
  * loc_train_step, mandatory with rows_next).  rows_next NULL = last step of the epoch.  Results equal loc_train_step's
  * up to the summation order of the BatchNorm gamma / beta gradient and of the layer-1 partial sums.
- * loc_train_chain_supported: width padding to 64, 128 or 256, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output.
+ * loc_train_chain_supported: width padding to 64, 128, 256 or 512, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output.
  * CONTRACT: a step with fwd_done != 0 must follow, on the same stream, a chained step whose rows_next / n_b_next /
  * bn_next_stats described it -- the hand-over lives in the workspace (layer-1 partial sums, scale/shift), so nothing that
  * uses net->ws (loc_train_step, loc_bn_epoch_stats, loc_predict without net->ws_predict) may run in between.  The library

@@ -1,6 +1,6 @@
-// Layer-1 backward + Adam of minibatch t CHAINED with the layer-1 forward of minibatch t + 1; widths that pad to 256, 128 or
-// 64 (round 4: NHT = 8, 4, 2 unit tiles; a workgroup then owns 1, 2 or 4 k-tiles at a time so that all eight of its waves
-// stream weights whatever the width)
+// Layer-1 backward + Adam of minibatch t CHAINED with the layer-1 forward of minibatch t + 1; widths that pad to 512, 256,
+// 128 or 64 (round 4: NHT = 16, 8, 4, 2 unit tiles; with fewer than 8 a workgroup owns 2 or 4 k-tiles at a time so that all
+// eight of its waves stream weights whatever the width, with 16 every wave streams two unit tiles per k-tile)
 // (reference: one `model.fit` step after another, /root/reference/locator/locator.py:367-376; layer 1 is
 // BatchNormalization + Dense(width, elu), :318-320).
 //
@@ -37,6 +37,15 @@
 // so the count stays 12).  A wave's forward accumulator covers its slot's k-tiles only, so the launch leaves KTW partial
 // groups per workgroup (partial[g * KTW + slot]) for l1_reduce_kernel.  The last super-tile may be short: its missing
 // slots run the same loads on dummy addresses, contribute zeros and store nothing.
+//
+// Width 512 (NHT = 16).  Sixteen waves would leave each 128 registers - less than the two weight / moment register sets, the
+// MFMA accumulators and the forward accumulators need - so the workgroup stays at eight waves and wave w streams unit tiles
+// w and w + 8 of every k-tile one after the other ("sub-steps"): the register sets keep alternating (tile w in A while
+// w + 8 lands in B, w + 8 in B while the next k-tile's w lands in A), every sub-step is the same "12 loads | wait for 12"
+// pattern, the wave adds its two (dgamma | dbeta) partials before they go to LDS, keeps two transposed W' tiles and two
+// forward accumulators, and everything per k-tile (barrier, gamma / beta Adam, small operands) happens after the second
+// sub-step.  dZ alone is 64 KB of LDS at this width, the kernel's 147 KB still fit one workgroup per compute unit.
+#include <type_traits>
 #include "common.h"
 #include "stack_tail.h"
 
@@ -107,8 +116,11 @@ __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4
 
 constexpr int CH_TP = 33;
 constexpr int CH_SM = 896;   // floats of one k-tile's small operands in LDS (see `sm` in the kernel)
+constexpr int ch_ktw(int nht) { return nht >= 8 ? 1 : 8 / nht; }     // k-tiles (slots) a workgroup owns at a time
+constexpr int ch_upw(int nht) { return nht > 8 ? nht / 8 : 1; }      // unit tiles a wave streams per k-tile (sub-steps)
 constexpr size_t ch_lds_floats(int nht) {
-    return 32 * (nht * 32 + 1) + 64 + 8 * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * (8 / nht) * CH_SM;
+    return 32 * (nht * 32 + 1) + 64 + 8 * ch_upw(nht) * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * ch_ktw(nht) * CH_SM +
+           (ch_upw(nht) > 1 ? nht * 32 : 0);
 }
 
 // The hand-counted wait: at most N vector-memory operations outstanding; the operands tie every register an untracked load
@@ -149,10 +161,12 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     int alpha_tab_len, const float* __restrict__ lr, const int* __restrict__ t_base, int t_off,
     float* __restrict__ partial_out, int n_tail, loc_dw_tail_args ta) {
     constexpr int Hp = NHT * 32, PZ = Hp + 1, TP = CH_TP;
-    constexpr int KTW = 8 / NHT;                 // k-tiles (slots) a workgroup owns at a time
+    constexpr int KTW = ch_ktw(NHT);             // k-tiles (slots) a workgroup owns at a time
+    constexpr int UPW = ch_upw(NHT);             // unit tiles a wave streams per k-tile, one after the other
+    constexpr int WPS = NHT / UPW;               // waves per slot
     constexpr int NROLE = 7 * KTW;               // loader roles per super-tile
     constexpr int RPW = (NROLE + 7) / 8;         // ... per wave
-    static_assert(NHT == 8 || NHT == 4 || NHT == 2, "unit tiles per k-tile");
+    static_assert(NHT == 16 || NHT == 8 || NHT == 4 || NHT == 2, "unit tiles per k-tile");
     // Trailing workgroups (n_tail of them): the step's other Adam tail -- hidden-layer dW / db, heads, batch loss
     // (stack_tail.h).  It depends on nothing this kernel writes.  Workgroups are dispatched in index order, so these start
     // when the first layer-1 workgroups retire: 3125 k-tiles over 256 workgroups leave most compute units idle during the
@@ -167,18 +181,19 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     float* dzl = smem;                                          // [32][PZ]   dZ of this step
     int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);        // [32]
     int* rown_l = rows_l + 32;                                  // [32]       rows of the next minibatch
-    float* Tt = reinterpret_cast<float*>(rown_l + 32);          // [8][32][TP] per-wave W' tile, [SNP][unit]
-    float* red = Tt + 8 * 32 * TP;                              // [2][8][64]  per-wave (dgamma | dbeta) partials, by k-tile parity
+    float* Tt = reinterpret_cast<float*>(rown_l + 32);          // [8][UPW][32][TP] per-wave W' tiles, [SNP][unit]
+    float* red = Tt + 8 * UPW * 32 * TP;                            // [2][8][64]  per-wave (dgamma | dbeta) partials, by k-tile parity
     float* ssl = red + 2 * 8 * 64;                              // [8][64]     per-wave (scale' | shift') of the next step
     // [2][KTW][CH_SM] the small operands of a k-tile (slot), fetched two super-tiles ahead by the loader roles (one to three
     // load instructions each instead of 26 per wave): bytes 0..1023 genotype tile of this minibatch [32 rows][32 SNPs],
     // 1024..2047 the same for the next minibatch, then floats [scale|shift|mean|rstd][32], (gamma|beta), their Adam
     // m, v [64] each, next [mean|var][32]
     float* sm = ssl + 8 * 64;
+    float* dzs_l = sm + 2 * KTW * CH_SM;                        // [Hp] column sums of dZ (UPW > 1 only: see dzs below)
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
-    const int ut = w % NHT, kq = w / NHT;        // this wave's unit tile, and its k-tile slot inside the super-tile
+    const int ut0 = w % WPS, kq = w / WPS;       // this wave's (first) unit tile, and its k-tile slot inside the super-tile
     const int nkt = Kp / KT, S = (nkt + KTW - 1) / KTW;
     // k-tile of slot `slot` of super-tile T, or -1 (no such super-tile, or past the end of a short last one)
     auto ktile = [&](int T, int slot) { return (T >= 0 && T < S && T * KTW + slot < nkt) ? T * KTW + slot : -1; };
@@ -186,12 +201,12 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     const bool chain = rows_next != nullptr;
 
     // byte offset of this lane's first 16 bytes of unit (kt, w) in each of W1S / m / v  (Kp * 1024 < 2^32: checked by the launcher)
-    auto unit_off = [&](int kt) { return (uint32_t)(((uint32_t)kt * NHT + ut) * 4096u + lane * 16u); };
-    auto load_unit = [&](int kt, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
+    auto unit_off = [&](int kt, int ut) { return (uint32_t)(((uint32_t)kt * NHT + ut) * 4096u + lane * 16u); };
+    auto load_unit = [&](int kt, int ut, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4]) {
         // 12 loads, ALWAYS (the wait counts depend on it).  kt < 0: nothing left to fetch -- the same 12 instructions with
         // ONE address for the whole wave (one 16-byte request each instead of 1 KB), a different line per wave so that
         // the 2048 waves do not queue on one channel; results unused
-        const uint32_t o = kt >= 0 ? unit_off(kt) : (uint32_t)((((uint32_t)blockIdx.x * 8 + w) & 2047u) * 64u);
+        const uint32_t o = kt >= 0 ? unit_off(kt, ut) : (uint32_t)((((uint32_t)blockIdx.x * 8 + w) & 2047u) * 64u);
         ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0>(vq[0], v1s, o);
         ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0>(vq[1], v1s, o);
         ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0>(vq[2], v1s, o);
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     };
     // The first unit is requested before anything else; the prologue ends with vmcnt(0).
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
-    load_unit(ktile((int)blockIdx.x, kq), wA, mA, vA);
+    load_unit(ktile((int)blockIdx.x, kq), ut0, wA, mA, vA);
 
     for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
     if (t < 32) {
@@ -217,9 +232,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         red[t] = sum;
     }
     __syncthreads();
-    float dzs[16];
+    // (a wave with two unit tiles re-reads them from LDS every sub-step instead: 32 more registers would spill)
+    float dzs_r[16];
+    if constexpr (UPW == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dzs[r] = red[ut * 32 + rowmap(r, hi)];
+        for (int r = 0; r < 16; ++r) dzs_r[r] = red[ut0 * 32 + rowmap(r, hi)];
+    } else {
+        if (t < Hp) dzs_l[t] = red[t];
+    }
 
     // gamma (lanes 0..31) or beta (lanes 32..63) of SNP jl of the tile: one Adam per lane.  beta / m_beta / v_beta sit Kp
     // floats behind gamma / m_gamma / v_gamma (loc_param_layout; checked by the launcher): one wave-uniform base each
@@ -299,30 +319,49 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 
     // bias of layer 1: db1[h] = sum_b dZ[b][h]   (workgroup 0, the waves of slot 0: wave <-> unit tile)
     if (blockIdx.x == 0 && kq == 0) {
-        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ut * 32 + jl];
-        s += __shfl_xor(s, 32);
-        if (hi == 0) {
-            const int h = ut * 32 + jl;
-            float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
-            adam_update(wv, mv, vv, s, alpha);
-            b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
+        for (int u = 0; u < UPW; ++u) {
+            const int ut = ut0 + WPS * u;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ut * 32 + jl];
+            s += __shfl_xor(s, 32);
+            if (hi == 0) {
+                const int h = ut * 32 + jl;
+                float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
+                adam_update(wv, mv, vv, s, alpha);
+                b1[h] = wv; m_b1[h] = mv; v_b1[h] = vv;
+            }
         }
     }
 
-    float* Tw = Tt + w * 32 * TP;
+    float* Tw0 = Tt + w * UPW * 32 * TP;
     float* ssw = ssl + w * 64;
     const bool row_next_ok = chain && jl < n_b_next;
 
-    f32x16 facc = {0};
+    f32x16 facc[UPW];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) facc[u] = f32x16{0};
+    float pg_acc = 0.f, pb_acc = 0.f;     // this wave's (dgamma | dbeta) partial over the sub-steps of a k-tile
 
-    // Vector-memory operations of one iteration, in program order (the hand-counted wait depends on it):
-    //   12 prefetch loads | wait | 12 stores of this unit | 3 small loads of tile + 2 | barrier | 0..5 small stores
-    auto step = [&](int T, int T_next, int T_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4], f32x4 (&vq)[4],
-                    f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
+    // Vector-memory operations of one sub-step, in program order (the hand-counted wait depends on it):
+    //   12 prefetch loads | wait | 12 stores of this unit | last sub-step of the k-tile: 3 small loads of tile + 2 per role |
+    //   barrier | 0..5 small stores
+    // SUB = which of the wave's UPW unit tiles of k-tile (T, slot kq) this is; the unit prefetched meanwhile is sub-step
+    // (SUB + 1) % UPW of super-tile T_pref (= T unless this is the last sub-step)
+    auto step = [&](auto sub_c, int T, int T_pref, int T_next, int T_next2, int par, f32x4 (&wq)[4], f32x4 (&mq)[4],
+                    f32x4 (&vq)[4], f32x4 (&wn)[4], f32x4 (&mn)[4], f32x4 (&vn)[4]) {
+        constexpr int SUB = decltype(sub_c)::value;
+        constexpr bool first = SUB == 0, last = SUB == UPW - 1;
+        const int ut = ut0 + WPS * SUB;
+        float* Tw = Tw0 + SUB * 32 * TP;
+        float dzs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dzs[r] = UPW == 1 ? dzs_r[r] : dzs_l[ut * 32 + rowmap(r, hi)];
         const int ktv = ktile(T, kq);
-        const bool valid = ktv >= 0;             // false only for the missing slots of a short last super-tile (wave-uniform)
+        // false only for the missing slots of a short last super-tile (wave-uniform); a workgroup that owns whole k-tiles
+        // (UPW > 1 implies KTW == 1) has none
+        const bool valid = UPW > 1 || ktv >= 0;
         const int kt = valid ? ktv : 0;
         const int k = kt * KT + jl;
         // this tile's small operands from LDS
@@ -338,7 +377,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // ONE wait per iteration, right after the next unit's 12 loads (always 12: dummies on the last tile): "at most 12
         // outstanding" proves every older load landed -- this unit (requested an iteration ago) and the next tile's small
         // operands ld0..2 (requested at the end of the previous iteration).
-        load_unit(ktile(T_next, kq), wn, mn, vn);
+        load_unit(ktile(T_pref, kq), ut0 + WPS * ((SUB + 1) % UPW), wn, mn, vn);
         ch_wait_unit<12>(wq, mq, vq, ld);
 
         // ONE fp32 MFMA chain per unit:  Gn[h][k] = sum_b dZ[b][h] xn[b][k]  (D[i = unit][j = SNP], contraction over the
@@ -359,12 +398,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             }
             pg += __shfl_xor(pg, 32);
             pb += __shfl_xor(pb, 32);
-            red[(par * 8 + w) * 64 + lane] = valid ? (hi ? pb : pg) : 0.f;
+            if (!first) { pg += pg_acc; pb += pb_acc; }
+            if (last) red[(par * 8 + w) * 64 + lane] = valid ? (hi ? pb : pg) : 0.f;
+            else { pg_acc = pg; pb_acc = pb; }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = fmaf(gam, g[r], bet * dzs[r]);
         // Adam on the weight tile, stores, and the tile's transpose for the next forward
-        const uint32_t so = unit_off(kt);
+        const uint32_t so = unit_off(kt, ut);
         auto adam4 = [&](int q) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -393,6 +434,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tw[jl * TP + rowmap(r, hi)] = wq[r >> 2][r & 3];   // T[SNP][unit]
         }
+        if (!last) return;            // the rest once per k-tile, after the wave's last unit tile
         // The next tile's small operands (landed: see the wait above) go to the other LDS buffer, then the request for
         // the tile after next.
         if (!(LOC_CHAIN_ABLATE & 2)) stage(par ^ 1, T_next);
@@ -403,12 +445,12 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         ch_lds_barrier();
 #endif
 
-        float dsum = red[(par * 8 + kq * NHT) * 64 + lane];       // the NHT waves of this slot, in wave order
+        float dsum = red[(par * 8 + kq * WPS) * 64 + lane];       // the waves of this slot, in wave order
 #pragma unroll
-        for (int w2 = 1; w2 < NHT; ++w2) dsum += red[(par * 8 + kq * NHT + w2) * 64 + lane];
+        for (int w2 = 1; w2 < WPS; ++w2) dsum += red[(par * 8 + kq * WPS + w2) * 64 + lane];
         adam_update(pv, pm, pvv, dsum, alpha);
         const bool live = valid && k < K;
-        if (ut == 0 && live) { gamma[gbo + k] = pv; m_gamma[gbo + k] = pm; v_gamma[gbo + k] = pvv; }
+        if (ut0 == 0 && live) { gamma[gbo + k] = pv; m_gamma[gbo + k] = pm; v_gamma[gbo + k] = pvv; }
         if (chain && valid && !(LOC_CHAIN_ABLATE & 4)) {
             const float other = __shfl_xor(pv, 32);
             const float gam = hi ? other : pv, bet = hi ? pv : other;
@@ -416,7 +458,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             float scn = gam * rstd;
             float shn = bet - nmu * scn;
             if (!live) { scn = 0.f; shn = 0.f; nmu = 0.f; rstd = 0.f; }
-            if (ut == 0) {
+            if (ut0 == 0) {
                 bn4[(hi ? Kp : 0) + k] = hi ? shn : scn;
                 bn4[(int64_t)(2 + hi) * Kp + k] = hi ? rstd : nmu;
             }
@@ -432,7 +474,9 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
                 for (int e = 0; e < 4; ++e) {
                     const float xb = (float)((xw >> (8 * e)) & 255u);
                     const float a = row_next_ok ? fmaf(xb, s4[e], h4[e]) : 0.f;   // rows beyond the next minibatch: staged from row 0, unused
-                    facc = mfma32(a, Tw[(16 * hi + 4 * j + e) * TP + jl], facc);
+#pragma unroll
+                    for (int u = 0; u < UPW; ++u)
+                        facc[u] = mfma32(a, Tw0[(u * 32 + 16 * hi + 4 * j + e) * TP + jl], facc[u]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -442,10 +486,21 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // workgroup g owns k-tiles g, g + G, g + 2G, ...: at any moment the G workgroups stream one contiguous G * 32 KB
     // window of W1 / m / v, which spreads over every HBM channel
     {
+        using sub0 = std::integral_constant<int, 0>;
+        using sub1 = std::integral_constant<int, 1>;
         for (int T = blockIdx.x; T < S; T += 2 * G) {
             auto nx = [&](int j) { return T + j * G < S ? T + j * G : -1; };
-            step(T, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
-            if (T + G < S) step(T + G, nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+            if constexpr (UPW == 1) {
+                step(sub0{}, T, nx(1), nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+                if (T + G < S) step(sub0{}, T + G, nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+            } else {
+                step(sub0{}, T, T, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+                step(sub1{}, T, nx(1), nx(1), nx(2), 0, wB, mB, vB, wA, mA, vA);
+                if (T + G < S) {
+                    step(sub0{}, T + G, T + G, nx(2), nx(3), 1, wA, mA, vA, wB, mB, vB);
+                    step(sub1{}, T + G, nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+                }
+            }
         }
     }
     // the last iteration's dummy requests are still in flight: nothing below may reuse their registers before they land
@@ -455,13 +510,15 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // (one partial group per k-tile slot of this workgroup: group g * KTW + slot)
         float* pout = partial_out + ((int64_t)blockIdx.x * KTW + kq) * 32 * Hp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + ut * 32 + jl] = facc[r];
+        for (int u = 0; u < UPW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + (ut0 + WPS * u) * 32 + jl] = facc[u][r];
     }
 }
 
-extern "C" int loc_l1_chain_supported(int Hp) { return Hp == 256 || Hp == 128 || Hp == 64; }
+extern "C" int loc_l1_chain_supported(int Hp) { return Hp == 512 || Hp == 256 || Hp == 128 || Hp == 64; }
 // partial groups the chained kernel leaves per workgroup (k-tile slots a workgroup owns at a time)
-extern "C" int loc_l1_chain_groups_per_workgroup(int Hp) { return loc_l1_chain_supported(Hp) ? 8 / (Hp / 32) : 0; }
+extern "C" int loc_l1_chain_groups_per_workgroup(int Hp) { return loc_l1_chain_supported(Hp) ? ch_ktw(Hp / 32) : 0; }
 
 int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n_b,
                                           const int32_t* rows_next, int n_b_next, const loc_dims* d, float* bn4,
@@ -471,7 +528,7 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
                                           const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                           int t_off, int grid, float* partial, int64_t partial_floats,
                                           const loc_tuning* tune, const loc_dw_tail_args* tail, void* stream) {
-    if (!loc_l1_chain_supported(d->Hp)) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 64, 128 or 256 (got %d)", d->Hp); return -1; }
+    if (!loc_l1_chain_supported(d->Hp)) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 64, 128, 256 or 512 (got %d)", d->Hp); return -1; }
     if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..32", n_b); return -1; }
     if (rows_next && (n_b_next < 1 || n_b_next > LOC_ROWS || !bn_next_stats)) {
         loc_set_error("loc_l1_backward_adam_chain: the next minibatch needs 1..32 rows (got %d) and its batch statistics",
@@ -491,7 +548,7 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
         loc_set_error("loc_l1_backward_adam_chain: more than 4M SNPs exceed the kernel's 32-bit byte offsets");
         return -1;
     }
-    const int nht = d->Hp / 32, ktw = 8 / nht;
+    const int nht = d->Hp / 32, ktw = ch_ktw(nht);
     const int nkt = d->Kp / KT, n_super = (nkt + ktw - 1) / ktw;
     if (grid < 1) grid = 1;
     if (grid > n_super) grid = n_super;
@@ -519,7 +576,8 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
     }
 #define LAUNCH_CHAIN(M)                                                                                            \
     {                                                                                                              \
-        if (nht == 8) LAUNCH_CHAIN_N(M, 8) else if (nht == 4) LAUNCH_CHAIN_N(M, 4) else LAUNCH_CHAIN_N(M, 2)       \
+        if (nht == 16) LAUNCH_CHAIN_N(M, 16) else if (nht == 8) LAUNCH_CHAIN_N(M, 8)                               \
+        else if (nht == 4) LAUNCH_CHAIN_N(M, 4) else LAUNCH_CHAIN_N(M, 2)                                          \
     }
     if (nht != 8) {                       // the cache-policy measurement switches exist for the default width only
         LAUNCH_CHAIN(13)

@@ -93,7 +93,7 @@ def test_codecs_library_loads_and_exports_its_entry_points(repo_root):
 
 def test_train_chain_supported_is_decided_by_shape_alone():
     """loc_train_chain_supported is host logic over the loc_net fields (no kernel, no device memory): width padding to
-    64, 128 or 256, at least one hidden layer, batch <= 32, Dropout not on the BatchNorm output, 16-byte row pitch, and the chained
+    64, 128, 256 or 512, at least one hidden layer, batch <= 32, Dropout not on the BatchNorm output, 16-byte row pitch, and the chained
     kernel's 32-bit byte offsets (Kp * 1024 < 2^32: just under 4.2 million SNPs)."""
     lib = _lib.load()
 
@@ -109,7 +109,8 @@ def test_train_chain_supported_is_decided_by_shape_alone():
     ok = lambda **kw: bool(lib.loc_train_chain_supported(C.byref(net(**kw))))
     assert ok() and ok(width=225) and ok(nlayers=2) and ok(drop=0.0) and ok(K=31)
     assert ok(width=64) and ok(width=33) and ok(width=128) and ok(width=97)        # round 4: 2 and 4 unit tiles
-    assert not ok(width=224) and not ok(width=257) and not ok(width=32) and not ok(width=512)
+    assert ok(width=512) and ok(width=481)                                         # ... and 16 (two per wave)
+    assert not ok(width=224) and not ok(width=257) and not ok(width=32) and not ok(width=513) and not ok(width=1024)
     assert not ok(nlayers=1) and ok(nlayers=1, drop=0.0) is False
     assert not ok(slot_rows=128)                                     # --batch_size > 32
     assert not ok(wht=None)                                          # no fused hidden stack

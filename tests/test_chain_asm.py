@@ -139,11 +139,12 @@ def _walk(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("nht", [8, 4, 2])
+@pytest.mark.parametrize("nht", [16, 8, 4, 2])
 def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_counted_wait(nht):
-    """Every width the chained kernel is built for (round 4: 8, 4, 2 unit tiles = widths padding to 256, 128, 64; a wave then
-    carries 1, 2 or 4 loader roles of 3 small loads each)."""
-    small = 3 * ((7 * (8 // nht) + 7) // 8)
+    """Every width the chained kernel is built for (round 4: 16, 8, 4, 2 unit tiles = widths padding to 512, 256, 128, 64; a
+    wave then carries 1, 1, 2 or 4 loader roles of 3 small loads each; with 16 unit tiles the loop body holds four sub-steps
+    of 12 loads, two of them followed by the small loads)."""
+    small = 3 * ((7 * max(8 // nht, 1) + 7) // 8)
     prog, lo, hi, n_loads, n_waits = _walk(_kernel_asm(nht))
     assert sum(1 for k, _, _ in prog[lo:hi + 1] if k == "aload") >= 2 * (12 + small), f"main loop with its 2 x (12 + {small}) loads not found"
     assert n_loads >= 3 * (12 + small) and n_waits >= 4

@@ -62,7 +62,7 @@ def _run_epochs(x, y, p, tr, va, perms, chain, drop_p, use_graph, seed=5):
     (3000, 2, 40, 0.0),         # no dropout, one full + one 8-row minibatch
     (2000, 3, 64, 0.25),        # nlayers 3: Dropout directly on layer 1's output (mask applied by the reduction)
 ])
-@pytest.mark.parametrize("width", [256, 128, 100, 64, 40])
+@pytest.mark.parametrize("width", [512, 490, 256, 128, 100, 64, 40])
 def test_chained_epochs_equal_unchained_epochs(K, nlayers, n_train, drop_p, width):
     """Widths padding to 256, 128 (100, 128) and 64 (40, 64): 8, 4, 2 unit tiles per k-tile; the narrower layers own 2 / 4
     k-tiles per workgroup at a time (round 4; K = 5000 and 40010 leave a short last super-tile for both)."""
@@ -107,7 +107,7 @@ def test_chained_epochs_equal_unchained_epochs_at_config4_width_of_snps():
     assert np.abs(p1["W"][0] - p["W"][0]).max() > 1e-4 and np.abs(p1["W"][0][-40:] - p["W"][0][-40:]).max() > 1e-4   # trained, to the last SNP
 
 
-@pytest.mark.parametrize("width", [256, 128, 64])
+@pytest.mark.parametrize("width", [512, 256, 128, 64])
 def test_chained_epochs_match_the_oracle_fit(width):
     """Chained schedule against oracle.fit with the same permutations and the device's dropout masks: 4 epochs x 4
     steps (last minibatch of 4 rows) at widths 256 / 128 / 64.  Tolerances of test_short_fit_trajectory_matches_oracle_fit."""
@@ -131,7 +131,7 @@ def test_chained_epochs_match_the_oracle_fit(width):
     assert rel.max() < 1e-3, rel.max()
 
 
-@pytest.mark.parametrize("width", [256, 128, 64])
+@pytest.mark.parametrize("width", [512, 256, 128, 64])
 def test_chained_graph_replay_equals_eager_enqueue(width):
     """The captured epoch (graph replay) and the eagerly enqueued one run the same chained launches: bit-identical."""
     K, nlayers = 3000, 4
@@ -150,9 +150,9 @@ def test_chain_is_refused_where_it_does_not_apply():
     net = build_net(x, y, p)
     assert not net.chain_supported()                                    # width 300 pads to 320: per-layer kernels
     assert not EpochRunner(net, np.arange(40), np.arange(40, 60), 32, chain=True).chain
-    x, y, p, rng = make_problem(60, 500, 512, 4, seed=1)
-    assert not build_net(x, y, p).chain_supported()                      # width 512: fused stack, unchained layer 1
-    for wdt in (64, 128):
+    x, y, p, rng = make_problem(60, 500, 1024, 4, seed=1)
+    assert not build_net(x, y, p).chain_supported()                      # width 1024: per-layer kernels
+    for wdt in (64, 128, 512):
         x, y, p, rng = make_problem(60, 500, wdt, 4, seed=1)
         assert build_net(x, y, p).chain_supported()                      # since round 4
     x, y, p, rng = make_problem(60, 500, 256, 1, seed=1)
@@ -168,10 +168,10 @@ def test_chain_is_refused_where_it_does_not_apply():
         net.train_step_chain(rows, 32, 1, torch.ones(32 * 256, dtype=torch.uint8, device="cuda"), loss, None, rows, 32, False)
 
 
-@pytest.mark.parametrize("width", [128, 64])
+@pytest.mark.parametrize("width", [512, 128, 64])
 def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps_narrow(width):
     """100,000 SNPs at widths 128 / 64: 1563 / 782 super-tiles over 256 workgroups, every iteration of the pipeline in
-    steady state, the last super-tile short (3,125 k-tiles is odd)."""
+    steady state, the last super-tile short (3,125 k-tiles is odd); at width 512: 3,125 k-tiles of two sub-steps per wave."""
     K, nlayers, n_train = 100000, 10, 96
     x, y, p, rng = make_problem(n_train + 20, K, width, nlayers, seed=width)
     tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
@@ -182,14 +182,16 @@ def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps_nar
     _assert_same_fit(p0, p1, m0, m1, v0, v1)
 
 
-@pytest.mark.parametrize("K,n_b,n_b_next", [(4000, 32, 32), (4000, 17, 5), (9990, 32, 32), (100000, 32, 10)])
-def test_chain_kernel_against_the_two_kernels_it_replaces(K, n_b, n_b_next):
+@pytest.mark.parametrize("K,n_b,n_b_next,width", [(4000, 32, 32, 256), (4000, 17, 5, 256), (9990, 32, 32, 256),
+                                                  (100000, 32, 10, 256), (4000, 32, 32, 512), (9990, 17, 5, 512),
+                                                  (100000, 32, 10, 512)])
+def test_chain_kernel_against_the_two_kernels_it_replaces(K, n_b, n_b_next, width):
     """loc_l1_backward_adam_chain through the C ABI against loc_l1_backward_adam followed by loc_l1_forward on the next
     minibatch, same inputs: W1 / m / v, b1, gamma / beta and their moments, the next step's [scale|shift|mean|rstd], and
     the next minibatch's layer-1 activations.  dZ1 and the batch statistics are synthetic (the kernels do not care)."""
     import ctypes as C
     from locator_amd import _lib
-    x, y, p, rng = make_problem(80, K, 256, 2, seed=K % 89 + n_b)
+    x, y, p, rng = make_problem(80, K, width, 2, seed=K % 89 + n_b)
     net = build_net(x, y, p, drop_p=0.0)
     lib, d, lay = net.lib, net.d, net.lay
     Kp, Hp = d.Kp, d.Hp
@@ -286,7 +288,7 @@ import torch
 from tests.gpu_util import build_net, make_problem
 from locator_amd.train import EpochRunner
 h = hashlib.sha256()
-for width, K in ((256, 40010), (128, 20000), (64, 9000)):
+for width, K in ((512, 30010), (256, 40010), (128, 20000), (64, 9000)):
     x, y, p, rng = make_problem(116, K, width, 4, seed=width)
     net = build_net(x, y, p, drop_p=0.25, seed=5)
     r = EpochRunner(net, np.arange(96), np.arange(96, 116), 32, use_graph=False, chain=True)
@@ -336,7 +338,7 @@ def _run_xchain(x, y, p, tr, va, perms, xchain, use_graph, width_seed=5):
     return net, hist, net.export_params(), m, v
 
 
-@pytest.mark.parametrize("width,K,n_train", [(256, 40010, 96), (256, 5000, 74), (128, 20000, 96), (64, 9000, 70)])
+@pytest.mark.parametrize("width,K,n_train", [(512, 30010, 96), (256, 40010, 96), (256, 5000, 74), (128, 20000, 96), (64, 9000, 70)])
 def test_cross_epoch_chaining_equals_the_per_epoch_schedule(width, K, n_train):
     """Round 4: the last step of an epoch also computes the first layer-1 forward of the next epoch (its rows and batch
     statistics are known an epoch early), so every epoch but the first starts from a hand-over instead of an unchained
