@@ -365,7 +365,7 @@ int loc_l1_backward_adam_main(const uint8_t* X, int64_t x_pitch, const int32_t* 
                               const float* lr, const int* t_base, int t_off, int grid, const loc_tuning* tune,
                               void* stream);
 
-/* Layer-1 backward + Adam of one minibatch CHAINED with the layer-1 forward of the next one (width padding to 256, 128
+/* Layer-1 backward + Adam of one minibatch CHAINED with the layer-1 forward of the next one (width padding to 512, 256, 128
  * or 64, n_b <= 32; locator.py:367-376: consecutive steps of model.fit).  One pass over W1 / m / v: Adam on W1 and b1, the
  * BatchNorm gamma / beta update of loc_l1_backward_adam, the next step's [scale|shift|mean|rstd] into bn4 (in place;
  * bn_next_stats = [mean|var] of the next minibatch), and -- rows_next non-NULL -- partial[g][32][256] of the next
