@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--snps", type=int, default=100_000)
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--lib", default=None, help="measurement switch: another build of liblocator_hip.so")
     a = ap.parse_args()
+    if a.lib:
+        from locator_amd import _lib
+        _lib.use_library(a.lib)
     import torch
 
     from locator_amd.net import LocatorNet
