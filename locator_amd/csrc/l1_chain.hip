@@ -120,7 +120,7 @@ constexpr int ch_ktw(int nht) { return nht >= 8 ? 1 : 8 / nht; }     // k-tiles 
 constexpr int ch_upw(int nht) { return nht > 8 ? nht / 8 : 1; }      // unit tiles a wave streams per k-tile (sub-steps)
 constexpr size_t ch_lds_floats(int nht) {
     return 32 * (nht * 32 + 1) + 64 + 8 * ch_upw(nht) * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * ch_ktw(nht) * CH_SM +
-           (ch_upw(nht) > 1 ? nht * 32 : 0);
+           (nht != 8 ? nht * 32 : 0);
 }
 
 // The hand-counted wait: at most N vector-memory operations outstanding; the operands tie every register an untracked load
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // 1024..2047 the same for the next minibatch, then floats [scale|shift|mean|rstd][32], (gamma|beta), their Adam
     // m, v [64] each, next [mean|var][32]
     float* sm = ssl + 8 * 64;
-    float* dzs_l = sm + 2 * KTW * CH_SM;                        // [Hp] column sums of dZ (UPW > 1 only: see dzs below)
+    float* dzs_l = sm + 2 * KTW * CH_SM;                        // [Hp] column sums of dZ (NHT != 8 only: see dzs below)
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
@@ -232,9 +232,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         red[t] = sum;
     }
     __syncthreads();
-    // (a wave with two unit tiles re-reads them from LDS every sub-step instead: 32 more registers would spill)
+    // (every width but 256 re-reads them from LDS at each use instead: two unit tiles per wave would need 32 registers, and the
+    // narrow widths' extra loader-role words already spill without the 16)
     float dzs_r[16];
-    if constexpr (UPW == 1) {
+    if constexpr (NHT == 8) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dzs_r[r] = red[ut0 * 32 + rowmap(r, hi)];
     } else {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         float* Tw = Tw0 + SUB * 32 * TP;
         float dzs[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dzs[r] = UPW == 1 ? dzs_r[r] : dzs_l[ut * 32 + rowmap(r, hi)];
+        for (int r = 0; r < 16; ++r) dzs[r] = NHT == 8 ? dzs_r[r] : dzs_l[ut * 32 + rowmap(r, hi)];
         const int ktv = ktile(T, kq);
         // false only for the missing slots of a short last super-tile (wave-uniform); a workgroup that owns whole k-tiles
         // (UPW > 1 implies KTW == 1) has none
