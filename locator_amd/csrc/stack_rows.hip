@@ -22,6 +22,19 @@
 #define SR_ROWS 32
 #define SR_PITCH 260     /* floats per activation row in LDS: 16-lane ds_read_b128 groups start 4 banks apart */
 
+// -DSR_STAMPS=<block>: a measurement build (tools/probes/sr_stamps.py) in which every wave of one workgroup leaves the cycle
+// counter at the phase boundaries of every layer
+#ifdef SR_STAMPS
+__device__ unsigned long long sr_stamp_buf[8 * 64];
+#define SR_STAMP(i)                                                                                       \
+    if ((int)blockIdx.x == SR_STAMPS && (threadIdx.x & 63) == 0) sr_stamp_buf[(threadIdx.x >> 6) * 64 + (i)] = __builtin_readcyclecounter();
+extern "C" int loc_debug_sr_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sr_stamp_buf), sizeof(unsigned long long) * 8 * 64);
+}
+#else
+#define SR_STAMP(i)
+#endif
+
 __device__ __forceinline__ void sr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
         const float* Wn = l < L ? Wc + HH : Wh;                // after the last layer: a dummy prefetch, never used
         const float bias = bh[(int64_t)(l - 2) * Hp + 32 * w + jl];
         const float* arow = act[cur] + jl * P + 128 * hi;      // this lane's row, its half of the k range
+        SR_STAMP(4 * (l - 2) + 0)
         f32x16 acc = {0};
 #pragma unroll 1
         for (int c = 0; c < 8; c += 2) {
@@ -106,12 +120,15 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
                 if (c + 3 < 8) load_chunk(Wc, c + 3, bB); else load_chunk(Wn, 1, bB);
             }
         }
+        SR_STAMP(4 * (l - 2) + 1)
         // bias + ELU -> the other activation buffer: lane holds unit 32 w + jl of rows rowmap(r, hi)
         float* out = act[cur ^ 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[rowmap(r, hi) * P + 32 * w + jl] = elu_f(acc[r] + bias);
         cur ^= 1;
+        SR_STAMP(4 * (l - 2) + 2)
         sr_lds_barrier();
+        SR_STAMP(4 * (l - 2) + 3)
     }
     asm volatile("" ::"v"(bA[0]), "v"(bB[0]));
 
@@ -154,6 +171,15 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
 // workgroups to fill the chip, and a workgroup's nine dependent layers take ~60 us whatever the row count)
 extern "C" int loc_stack_rows_min_rows(void) { return 3072; }
 extern "C" int loc_stack_rows_supported(int Hp, int L) { return Hp == SR_HP && L >= 2; }
+
+#ifdef SR_STAMPS
+extern "C" int loc_debug_sr_occupancy(int lds_bytes) {
+    int nb = -1;
+    LOC_ENSURE_LDS(stack_rows_eval_kernel, (size_t)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stack_rows_eval_kernel, 512, (size_t)lds_bytes) != hipSuccess) return -2;
+    return nb;
+}
+#endif
 
 int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8, const float* rd_b1,
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
