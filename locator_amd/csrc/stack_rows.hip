@@ -55,7 +55,11 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
     auto load_chunk = [&](const float* __restrict__ W, int c, float (&b)[16]) {
         const float* p = W + (int64_t)(16 * c + 128 * hi) * Hp + 32 * w + jl;
 #pragma unroll
+#if defined(SR_ABLATE) && SR_ABLATE == 1
+        for (int e = 0; e < 16; ++e) b[e] = p[(int64_t)(e & 3) * Hp];               // timing only (wrong results): 4 loads per chunk
+#else
         for (int e = 0; e < 16; ++e) b[e] = p[(int64_t)e * Hp];
+#endif
     };
     float bA[16], bB[16];
     load_chunk(Wh, 0, bA);
