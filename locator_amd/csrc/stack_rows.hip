@@ -11,9 +11,14 @@
 // order of the sums - and streams the weights once per 32 rows (16 x less L2 traffic); activations never leave the LDS.
 //   wave w (of 8) owns output units [32 w, 32 w + 32) of every layer:  D[i = row][j = unit] += A[i][k] B[k][j], two k per
 //   MFMA: k = s + 128 hi for lane half hi, s = 0..127, so a lane's A values are CONSECUTIVE floats of its row in the LDS
-//   tile (one ds_read_b128 per four MFMAs) and its B values are W[k][32 w + jl]: two fully used 128-byte lines per request.
-//   Weight requests run 16 MFMAs (one register set) ahead, across layer boundaries (the weights do not depend on
-//   the activations).
+//   tile (one ds_read_b128 per four MFMAs) and its B values are W[k][32 w + jl].
+//   The weights reach that layout through a per-wave LDS stage (round 4, late): fetched as 16-byte-per-lane requests (1 KB
+//   contiguous runs, 4 per chunk of 16 steps) three chunks ahead, across layer boundaries (they do not depend on the
+//   activations), parked in the stage, read back one value per MFMA.  Fetched straight into the MFMA layout (one 4-byte load
+//   per MFMA and lane) the kernel made 1,024 vector-memory instructions per layer and compute unit and its MFMA loop followed
+//   their NUMBER - 18-26k cycles per layer where the MFMAs need 16.4k, 19.5k with a quarter of the loads (timing build
+//   `make sr_stamps XDEF=-DSR_ABLATE=1`), unchanged by where the lines come from, by the prefetch depth, by a second
+//   accumulator chain or by earlier LDS reads (tools/probes/sr_stamps.py).  Staged: 18-22k.
 // Optional input stage as in stack_fused.hip: the many-row GEMM's SNP-group partial sums are added up here (+ shift + b1,
 // ELU), same association as l1_gemm_reduce_kernel.
 #include "common.h"
@@ -44,26 +49,52 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
     const float* __restrict__ bb, int L, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
     float* __restrict__ yhat, float* __restrict__ dist) {
     constexpr int Hp = SR_HP, P = SR_PITCH;
-    extern __shared__ __attribute__((aligned(16))) float sr_smem[];        // two activation tiles + the head partials: 68.6 KB
+    // two activation tiles + the head partials (68.6 KB) + two weight-chunk stages per wave (67.6 KB)
+    extern __shared__ __attribute__((aligned(16))) float sr_smem[];
     float (*act)[SR_ROWS * P] = reinterpret_cast<float (*)[SR_ROWS * P]>(sr_smem);
     float (*hp)[SR_ROWS][2] = reinterpret_cast<float (*)[SR_ROWS][2]>(sr_smem + 2 * SR_ROWS * P);
+    float* wst = sr_smem + 2 * SR_ROWS * P + 8 * SR_ROWS * 2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, jl = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * SR_ROWS;
     const int64_t HH = (int64_t)Hp * Hp;
 
-    // weight stream: chunk c of a layer = steps s = 16 c .. 16 c + 15, lane value W[(s + 128 hi) * Hp + 32 w + jl]
-    auto load_chunk = [&](const float* __restrict__ W, int c, float (&b)[16]) {
-        const float* p = W + (int64_t)(16 * c + 128 * hi) * Hp + 32 * w + jl;
+    // weight stream: chunk c of a layer = steps s = 16 c .. 16 c + 15 for both lane halves: the 32 rows W[16 c + r + 128 h][32 w ..
+    // 32 w + 31] (r < 16, h < 2), 128 bytes each.  One 4-byte load per MFMA and lane - the layout the MFMA wants - makes 1,024
+    // vector-memory instructions per layer and compute unit, and the MFMA loop was bound by their number (see the header).  So a
+    // chunk travels as FOUR 16-byte loads per lane (lane = 8 rows x 8 column quads: 1 KB contiguous runs), is parked in a
+    // per-wave LDS stage [32 rows][32] and read back one value per MFMA: LDS operations of one wave execute in order, so the
+    // wave needs no barrier between its own stage writes and reads, and nobody else touches its stage.
+    constexpr int WS = 32 * 32 + 32;                     // floats per stage; rows 16..31 (lane half 1) shifted by 32 floats = 32 banks
+    float* stg = wst + w * 2 * WS;
+    const int grow = lane >> 3, gcol = 4 * (lane & 7);   // this lane's row (of 8 per request) and column quad
+    f32x4 g[4];
+    auto gload = [&](const float* __restrict__ W, int c) {
 #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ri = 8 * q + grow;                 // 0..31: half ri >> 4, step ri & 15
 #if defined(SR_ABLATE) && SR_ABLATE == 1
-        for (int e = 0; e < 16; ++e) b[e] = p[(int64_t)(e & 3) * Hp];               // timing only (wrong results): 4 loads per chunk
+            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(128 * (ri >> 4)) * Hp + 32 * w + gcol);   // timing only (wrong results)
 #else
-        for (int e = 0; e < 16; ++e) b[e] = p[(int64_t)e * Hp];
+            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * c + (ri & 15) + 128 * (ri >> 4)) * Hp + 32 * w + gcol);
 #endif
+        }
+    };
+    auto sput = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ri = 8 * q + grow;
+            *reinterpret_cast<f32x4*>(stg + buf * WS + ri * 32 + (ri >> 4) * 32 + gcol) = g[q];
+        }
+    };
+    auto bget = [&](int buf, float (&bv)[16]) {
+        const float* p = stg + buf * WS + (hi * 16) * 32 + hi * 32 + jl;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = p[e * 32];
     };
     float bA[16], bB[16];
-    load_chunk(Wh, 0, bA);
-    load_chunk(Wh, 1, bB);
+    gload(Wh, 0); sput(0);
+    gload(Wh, 1); sput(1);
+    gload(Wh, 2);
 
     // ---- input: rows of this workgroup -> act[0]
     if (rd_partial != nullptr) {
@@ -98,6 +129,7 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
 
     // ---- layers 2..L
     int cur = 0;
+    bget(0, bA);
     for (int l = 2; l <= L; ++l) {
         const float* Wc = Wh + (int64_t)(l - 2) * HH;
         const float* Wn = l < L ? Wc + HH : Wh;                // after the last layer: a dummy prefetch, never used
@@ -105,23 +137,29 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
         const float* arow = act[cur] + jl * P + 128 * hi;      // this lane's row, its half of the k range
         SR_STAMP(4 * (l - 2) + 0)
         f32x16 acc = {0};
+        // chunk c (even) sits in bA and came from stage 0, chunk c + 1 goes stage 1 -> bB; `g` holds chunk c + 2 on entry.  After
+        // the last chunk of a layer the stream continues with the next layer's first chunks (they do not depend on activations).
 #pragma unroll 1
         for (int c = 0; c < 8; c += 2) {
             {
+                bget(1, bB);
                 f32x4 a4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + 16 * c + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc = mfma32(a4[e >> 2][e & 3], bA[e], acc);
-                if (c + 2 < 8) load_chunk(Wc, c + 2, bA); else load_chunk(Wn, 0, bA);
+                sput(0);                                       // chunk c + 2 (stage 0 was read into bA an iteration ago)
+                if (c + 3 < 8) gload(Wc, c + 3); else gload(Wn, c + 3 - 8);
             }
             {
+                bget(0, bA);                                   // chunk c + 2
                 f32x4 a4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + 16 * (c + 1) + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc = mfma32(a4[e >> 2][e & 3], bB[e], acc);
-                if (c + 3 < 8) load_chunk(Wc, c + 3, bB); else load_chunk(Wn, 1, bB);
+                sput(1);                                       // chunk c + 3
+                if (c + 4 < 8) gload(Wc, c + 4); else gload(Wn, c + 4 - 8);
             }
         }
         SR_STAMP(4 * (l - 2) + 1)
@@ -134,7 +172,7 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
         sr_lds_barrier();
         SR_STAMP(4 * (l - 2) + 3)
     }
-    asm volatile("" ::"v"(bA[0]), "v"(bB[0]));
+    asm volatile("" ::"v"(bA[0]), "v"(bB[0]), "v"(g[0]));
 
     // ---- Dense(2), Dense(2), distance (locator.py:324-325, :314-315): per row, fixed summation order
     {
@@ -188,7 +226,7 @@ extern "C" int loc_debug_sr_occupancy(int lds_bytes) {
 int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8, const float* rd_b1,
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
                    int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
-    constexpr size_t lds = (2 * SR_ROWS * SR_PITCH + 8 * SR_ROWS * 2) * sizeof(float);
+    constexpr size_t lds = (2 * SR_ROWS * SR_PITCH + 8 * SR_ROWS * 2 + 8 * 2 * (32 * 32 + 32)) * sizeof(float);
     LOC_ENSURE_LDS(stack_rows_eval_kernel, lds);
     hipLaunchKernelGGL(stack_rows_eval_kernel, dim3((n_b + SR_ROWS - 1) / SR_ROWS), dim3(512), lds, (hipStream_t)stream, a1,
                        rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist);
