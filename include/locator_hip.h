@@ -139,7 +139,8 @@ typedef struct loc_net {
     int l1_fwd_grid;         /* workgroups of the layer-1 forward (<= LOC_MAX_FWD_GRID) */
     int l1_bwd_grid;         /* workgroups of the layer-1 backward                      */
     int slot_rows;           /* rows per activation slot of the training scratch: 0 or 32 (--batch_size <= 32),
-                                LOC_BATCH_SLOT when --batch_size is 33..LOC_MAX_BATCH, or --batch_size rounded up to a
+                                64 or LOC_BATCH_SLOT when --batch_size is 33..64 / 65..LOC_MAX_BATCH (the same 128-row scratch
+                                layout; 64 lets steps of two 32-row blocks be chained), or --batch_size rounded up to a
                                 multiple of 128 above that (the workspace then comes from loc_workspace_floats_batch) */
     int predict_pieces;      /* bf16 pieces per weight in the large-M inference forward: 3 = exact fp32
                                 products (default when 0), 2 = ~2^-17, 1 = plain bf16 weights; -1 forces the
@@ -469,7 +470,8 @@ int loc_train_step(const loc_net* net, const int32_t* rows, int n_b, int t_off, 
  * of running the layer-1 forward.  The epoch-level BN statistics are required (bn_ready is implied; bn_next_stats as in
  * loc_train_step, mandatory with rows_next).  rows_next NULL = last step of the epoch.  Results equal loc_train_step's
  * up to the summation order of the BatchNorm gamma / beta gradient and of the layer-1 partial sums.
- * loc_train_chain_supported: width padding to 64, 128, 256 or 512, nlayers >= 2, batch <= 32, Dropout not on the BatchNorm output.
+ * loc_train_chain_supported: width padding to 64, 128, 256 or 512, nlayers >= 2, batch <= 32 (<= 64 at width 256: net->slot_rows =
+ * 64, two 32-row blocks per step, the partial sums then [group][64][Hp]), Dropout not on the BatchNorm output.
  * CONTRACT: a step with fwd_done != 0 must follow, on the same stream, a chained step whose rows_next / n_b_next /
  * bn_next_stats described it -- the hand-over lives in the workspace (layer-1 partial sums, scale/shift), so nothing that
  * uses net->ws (loc_train_step, loc_bn_epoch_stats, loc_predict without net->ws_predict) may run in between.  The library

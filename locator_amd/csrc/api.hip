@@ -124,12 +124,16 @@ static int chain_grid_of(const loc_net* net) {
 }
 // layer-1 partial groups a chained step leaves for the reduction (workgroups x k-tile slots per workgroup)
 static int chain_groups_of(const loc_net* net) { return chain_grid_of(net) * loc_l1_chain_groups_per_workgroup(net->d.Hp); }
+// 32-row blocks a chained step carries: 1, or 2 for --batch_size 33..64 (net->slot_rows = 64; width 256 only)
+#define LOC_CHAIN_MAX_ROWS 64
+static int chain_rb_of(const loc_net* net) { return net->slot_rows > LOC_ROWS ? 2 : 1; }
 
 extern "C" int loc_train_chain_supported(const loc_net* net) {
     const loc_dims* d = &net->d;
     const bool in_drop = net->drop_p > 0.f && d->n_pre == 0;
     return d->L >= 2 && net->wht && loc_stack_fused_supported(d->Hp) && loc_l1_chain_supported(d->Hp) &&
-           net->slot_rows <= LOC_ROWS && !in_drop && (int64_t)chain_groups_of(net) * 32 * d->Hp <= partial_floats_of(d) &&
+           (net->slot_rows <= LOC_ROWS || (net->slot_rows <= LOC_CHAIN_MAX_ROWS && d->Hp == 256)) && !in_drop &&
+           (int64_t)chain_groups_of(net) * 32 * chain_rb_of(net) * d->Hp <= partial_floats_of(d) &&
            (int64_t)d->Kp * 1024 < ((int64_t)1 << 32) && (net->x_pitch % 16) == 0;
 }
 
@@ -178,8 +182,8 @@ static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int
     if (chain && fwd_done) {
         // the previous step's chained kernel left this minibatch's layer-1 partial sums: only add them up
         const bool dr = use_drop && npre == 1;
-        TRY(loc_l1_reduce_launch_drop(w.partial, chain_groups_of(net), 32, Hp, P + lay.b1, act(1), dr ? w.adrop : nullptr,
-                                      dr ? mask : nullptr, ks, stream));
+        TRY(loc_l1_reduce_launch_drop(w.partial, chain_groups_of(net), 32 * chain_rb_of(net), Hp, P + lay.b1, act(1),
+                                      dr ? w.adrop : nullptr, dr ? mask : nullptr, ks, stream));
     } else if (n_b > LOC_ROWS) {
         // large-M forward, exact fp32 products (3 bf16 pieces); fills whole 128-row tiles of the activation slot
         TRY(loc_l1_forward_rows(net->X, net->x_pitch, rows, n_b, d, w.bn4, P + lay.w1, P + lay.b1, w.partial,
@@ -218,7 +222,7 @@ static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int
                                 P + lay.w1, M + lay.w1, V + lay.w1, P + lay.gamma, P + lay.beta, M + lay.gamma,
                                 V + lay.gamma, M + lay.beta, V + lay.beta, P + lay.b1, M + lay.b1, V + lay.b1, at, atl,
                                 net->lr, net->t_base, t_off, chain_grid_of(net), w.partial, w.partial_floats, &net->tune,
-                                merged ? &ta : nullptr, stream));
+                                merged ? &ta : nullptr, chain_rb_of(net), stream));
             if (ev_l1b1) (void)hipEventRecord((hipEvent_t)ev_l1b1, (hipStream_t)stream);
             if (!merged)
                 TRY(loc_stack_dw_adam_tail(Hp, L, npre, n_b, slot, use_drop ? 1 : 0, w.acts, w.adrop, w.dz, w.head_out, P,
@@ -294,11 +298,14 @@ extern "C" int loc_train_step_chain(const loc_net* net, const int32_t* rows, int
                                     float* loss_out, const float* bn_next_stats, const int32_t* rows_next,
                                     int n_b_next, int fwd_done, void* ev_l1b0, void* ev_l1b1, void* stream) {
     if (!loc_train_chain_supported(net)) {
-        loc_set_error("loc_train_step_chain: needs a width that pads to 64, 128 or 256, nlayers >= 2, --batch_size <= 32 and no "
-                      "Dropout on the BatchNorm output (loc_train_chain_supported)");
+        loc_set_error("loc_train_step_chain: needs a width that pads to 64, 128, 256 or 512, nlayers >= 2, --batch_size <= 32 (<= 64 "
+                      "at width 256) and no Dropout on the BatchNorm output (loc_train_chain_supported)");
         return -1;
     }
-    if (n_b > LOC_ROWS) { loc_set_error("loc_train_step_chain: n_b=%d out of 1..32", n_b); return -1; }
+    if (n_b > LOC_ROWS * chain_rb_of(net)) {
+        loc_set_error("loc_train_step_chain: n_b=%d out of 1..%d", n_b, LOC_ROWS * chain_rb_of(net));
+        return -1;
+    }
     if (rows_next && !bn_next_stats) {
         loc_set_error("loc_train_step_chain: rows_next needs the next minibatch's batch statistics");
         return -1;

@@ -118,9 +118,12 @@ constexpr int CH_TP = 33;
 constexpr int CH_SM = 896;   // floats of one k-tile's small operands in LDS (see `sm` in the kernel)
 constexpr int ch_ktw(int nht) { return nht >= 8 ? 1 : 8 / nht; }     // k-tiles (slots) a workgroup owns at a time
 constexpr int ch_upw(int nht) { return nht > 8 ? nht / 8 : 1; }      // unit tiles a wave streams per k-tile (sub-steps)
-constexpr size_t ch_lds_floats(int nht) {
-    return 32 * (nht * 32 + 1) + 64 + 8 * ch_upw(nht) * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * ch_ktw(nht) * CH_SM +
-           (nht != 8 ? nht * 32 : 0);
+// rb = 32-row blocks per minibatch (1: --batch_size <= 32; 2: 33..64, width 256 only): dZ, the row lists and the two genotype
+// tiles of a k-tile's small operands grow with it
+constexpr int ch_smf(int rb) { return CH_SM + 512 * (rb - 1); }       // floats of one k-tile's small operands
+constexpr size_t ch_lds_floats(int nht, int rb = 1) {
+    return 32 * rb * (nht * 32 + 1) + 64 * rb + 8 * ch_upw(nht) * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * ch_ktw(nht) * ch_smf(rb) +
+           ((nht != 8 || rb > 1) ? nht * 32 : 0);
 }
 
 // The hand-counted wait: at most N vector-memory operations outstanding; the operands tie every register an untracked load
@@ -150,7 +153,7 @@ __device__ __forceinline__ void ch_wait_unit(f32x4 (&a)[4], f32x4 (&b)[4], f32x4
                  : "memory");
 }
 
-template <int NTM, int NHT>
+template <int NTM, int NHT, int RB>
 __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     const uint8_t* __restrict__ X, int64_t pitch, const int32_t* __restrict__ rows, int n_b,
     const int32_t* __restrict__ rows_next, int n_b_next, int K, int Kp, float* bn4,
@@ -164,9 +167,15 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     constexpr int KTW = ch_ktw(NHT);             // k-tiles (slots) a workgroup owns at a time
     constexpr int UPW = ch_upw(NHT);             // unit tiles a wave streams per k-tile, one after the other
     constexpr int WPS = NHT / UPW;               // waves per slot
-    constexpr int NROLE = 7 * KTW;               // loader roles per super-tile
+    constexpr int NR = 32 * RB;                  // rows the workgroup is built for (RB row blocks of 32)
+    constexpr int NK = 4 * RB + 3;               // loader roles per k-tile: 2 RB + 2 RB genotype pieces, bn4, gamma / beta, next stats
+    constexpr int NROLE = NK * KTW;              // loader roles per super-tile
     constexpr int RPW = (NROLE + 7) / 8;         // ... per wave
+    constexpr int SMF = ch_smf(RB);              // floats of one k-tile's small operands
+    constexpr int FO = 512 * (RB - 1);           // shift of their float section behind the (RB times larger) genotype tiles
+    constexpr bool DZS_REG = NHT == 8 && RB == 1;   // dZ column sums in registers (else re-read from LDS)
     static_assert(NHT == 16 || NHT == 8 || NHT == 4 || NHT == 2, "unit tiles per k-tile");
+    static_assert(RB == 1 || (RB == 2 && NHT == 8), "row blocks: two at width 256 only");
     // Trailing workgroups (n_tail of them): the step's other Adam tail -- hidden-layer dW / db, heads, batch loss
     // (stack_tail.h).  It depends on nothing this kernel writes.  Workgroups are dispatched in index order, so these start
     // when the first layer-1 workgroups retire: 3125 k-tiles over 256 workgroups leave most compute units idle during the
@@ -174,14 +183,15 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     const int G = (int)gridDim.x - n_tail;
     if ((int)blockIdx.x >= G) {
         loc_gb_tail none = {};
-        stack_dw_all_body<NHT, 1>((int)blockIdx.x - G, ta, none);
+        // (two row blocks: a short last minibatch uses one, so the tail counts its blocks at run time)
+        stack_dw_all_body<NHT, RB == 1 ? 1 : 0>((int)blockIdx.x - G, ta, none);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dzl = smem;                                          // [32][PZ]   dZ of this step
-    int* rows_l = reinterpret_cast<int*>(dzl + 32 * PZ);        // [32]
-    int* rown_l = rows_l + 32;                                  // [32]       rows of the next minibatch
-    float* Tt = reinterpret_cast<float*>(rown_l + 32);          // [8][UPW][32][TP] per-wave W' tiles, [SNP][unit]
+    float* dzl = smem;                                          // [NR][PZ]   dZ of this step
+    int* rows_l = reinterpret_cast<int*>(dzl + NR * PZ);        // [NR]
+    int* rown_l = rows_l + NR;                                  // [NR]       rows of the next minibatch
+    float* Tt = reinterpret_cast<float*>(rown_l + NR);          // [8][UPW][32][TP] per-wave W' tiles, [SNP][unit]
     float* red = Tt + 8 * UPW * 32 * TP;                            // [2][8][64]  per-wave (dgamma | dbeta) partials, by k-tile parity
     float* ssl = red + 2 * 8 * 64;                              // [8][64]     per-wave (scale' | shift') of the next step
     // [2][KTW][CH_SM] the small operands of a k-tile (slot), fetched two super-tiles ahead by the loader roles (one to three
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // 1024..2047 the same for the next minibatch, then floats [scale|shift|mean|rstd][32], (gamma|beta), their Adam
     // m, v [64] each, next [mean|var][32]
     float* sm = ssl + 8 * 64;
-    float* dzs_l = sm + 2 * KTW * CH_SM;                        // [Hp] column sums of dZ (NHT != 8 only: see dzs below)
+    float* dzs_l = sm + 2 * KTW * SMF;                          // [Hp] column sums of dZ (unless DZS_REG: see dzs below)
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
@@ -216,8 +226,15 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
     load_unit(ktile((int)blockIdx.x, kq), ut0, wA, mA, vA);
 
-    for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
-    if (t < 32) {
+    if constexpr (RB == 1) {
+        for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
+    } else {
+        // the stack kernel carries (and zeroes beyond n_b) the rows of the 32-row blocks IN USE only: a short last minibatch
+        // leaves the other block's dZ rows stale
+        const int n_used = 32 * ((n_b + 31) / 32);
+        for (int i = t; i < NR * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = (i / Hp) < n_used ? dz1[i] : 0.f;
+    }
+    if (t < NR) {
         rows_l[t] = t < n_b ? rows[t] : 0;
         rown_l[t] = (chain && t < n_b_next) ? rows_next[t] : 0;
     }
@@ -228,14 +245,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     if (t < Hp) {
         float sum = 0.f;
 #pragma unroll 8
-        for (int b = 0; b < 32; ++b) sum += dzl[b * PZ + t];
+        for (int b = 0; b < NR; ++b) sum += dzl[b * PZ + t];
         red[t] = sum;
     }
     __syncthreads();
     // (every width but 256 re-reads them from LDS at each use instead: two unit tiles per wave would need 32 registers, and the
     // narrow widths' extra loader-role words already spill without the 16)
     float dzs_r[16];
-    if constexpr (NHT == 8) {
+    if constexpr (DZS_REG) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dzs_r[r] = red[ut0 * 32 + rowmap(r, hi)];
     } else {
@@ -257,22 +274,22 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // three 4-byte loads per role and lane, ALWAYS; the role (and "nothing to fetch") only chooses the addresses
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            const int role = w + 8 * rr, slot = role / 7, kind = role - 7 * slot;
+            const int role = w + 8 * rr, slot = role / NK, kind = role - NK * slot;
             const int kt = role < NROLE ? ktile(T, slot) : -1;
             const int ktc = kt >= 0 ? kt : 0;
             const int k = ktc * KT + jl;
             const void *a0 = alpha_tab + w, *a1 = a0, *a2 = a0;        // every "nothing to fetch" case: one read-only word per wave
             if (kt >= 0) {
-                if (kind <= 3) {
-                    const int pc = (kind & 1) * 64 + lane;             // 8-byte piece of the [32 rows][32 bytes] tile
-                    const int row = kind <= 1 ? rows_l[pc >> 2] : rown_l[pc >> 2];   // (no next minibatch: row 0, unused)
+                if (kind < 4 * RB) {
+                    const int pc = (kind & (2 * RB - 1)) * 64 + lane;  // 8-byte piece of the [NR rows][32 bytes] tile
+                    const int row = kind < 2 * RB ? rows_l[pc >> 2] : rown_l[pc >> 2];   // (no next minibatch: row 0, unused)
                     const uint8_t* a = X + (int64_t)row * pitch + (int64_t)ktc * KT + 8 * (pc & 3);
                     a0 = a; a1 = a + 4; a2 = a;
-                } else if (kind == 4) {
+                } else if (kind == 4 * RB) {
                     a0 = bn4 + (int64_t)hi * Kp + k; a1 = bn4 + (int64_t)(2 + hi) * Kp + k; a2 = a0;
-                } else if (kind == 5) {
+                } else if (kind == 4 * RB + 1) {
                     a0 = gamma + gbo + k; a1 = m_gamma + gbo + k; a2 = v_gamma + gbo + k;
-                } else if (kind == 6 && chain) {
+                } else if (kind == 4 * RB + 2 && chain) {
                     a0 = next_stats + (int64_t)hi * Kp + k; a1 = a0; a2 = a0;
                 }
             }
@@ -282,29 +299,31 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     auto stage = [&](int buf, int T) {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            const int role = w + 8 * rr, slot = role / 7, kind = role - 7 * slot;
+            const int role = w + 8 * rr, slot = role / NK, kind = role - NK * slot;
             if (role >= NROLE || ktile(T, slot) < 0) continue;
             const uint32_t ld0 = ld[rr][0], ld1 = ld[rr][1], ld2 = ld[rr][2];
-            float* b = sm + (buf * KTW + slot) * CH_SM;
-            if (kind <= 1) {
+            float* b = sm + (buf * KTW + slot) * SMF;
+            float* bf = b + FO;                       // the float section (offsets as for one row block)
+            if (kind < 2 * RB) {
                 // this minibatch's tile goes in TRANSPOSED, [SNP][32 bytes], the byte of row b at position
                 // 16 * ((b >> 2) & 1) + (b & 3) + 4 * (b >> 3): lane (SNP jl, half hi) then reads its 16 rows rowmap(r, hi),
                 // r = 0..15, as one 16-byte word
+                // (RB row blocks: [SNP][RB][32 bytes])
                 uint8_t* xb = reinterpret_cast<uint8_t*>(b);
-                const int pc = (kind & 1) * 64 + lane, row = pc >> 2, snp0 = 8 * (pc & 3);
-                const int pos = 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3);
+                const int pc = (kind & (2 * RB - 1)) * 64 + lane, row = pc >> 2, snp0 = 8 * (pc & 3), r5 = RB == 1 ? row : (row & 31);
+                const int pos = (RB == 1 ? 0 : 32 * (row >> 5)) + 16 * ((r5 >> 2) & 1) + (r5 & 3) + 4 * (r5 >> 3);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[(snp0 + e) * 32 + pos] = (uint8_t)(((e < 4 ? ld0 : ld1) >> (8 * (e & 3))) & 255u);
-            } else if (kind <= 3) {
+                for (int e = 0; e < 8; ++e) xb[(snp0 + e) * NR + pos] = (uint8_t)(((e < 4 ? ld0 : ld1) >> (8 * (e & 3))) & 255u);
+            } else if (kind < 4 * RB) {
                 uint2 v; v.x = ld0; v.y = ld1;
-                *reinterpret_cast<uint2*>(b + 256 + ((kind & 1) * 64 + lane) * 2) = v;
-            } else if (kind == 4) {
-                b[512 + lane] = bitsf(ld0);
-                b[576 + lane] = bitsf(ld1);
-            } else if (kind == 5) {
-                b[640 + lane] = bitsf(ld0); b[704 + lane] = bitsf(ld1); b[768 + lane] = bitsf(ld2);
+                *reinterpret_cast<uint2*>(b + 256 * RB + ((kind & (2 * RB - 1)) * 64 + lane) * 2) = v;
+            } else if (kind == 4 * RB) {
+                bf[512 + lane] = bitsf(ld0);
+                bf[576 + lane] = bitsf(ld1);
+            } else if (kind == 4 * RB + 1) {
+                bf[640 + lane] = bitsf(ld0); bf[704 + lane] = bitsf(ld1); bf[768 + lane] = bitsf(ld2);
             } else {
-                b[832 + lane] = bitsf(ld0);
+                bf[832 + lane] = bitsf(ld0);
             }
         }
     };
@@ -324,9 +343,13 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         for (int u = 0; u < UPW; ++u) {
             const int ut = ut0 + WPS * u;
             float s = 0.f;
+            if constexpr (RB == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ut * 32 + jl];
-            s += __shfl_xor(s, 32);
+                for (int r = 0; r < 16; ++r) s += dzl[rowmap(r, hi) * PZ + ut * 32 + jl];
+                s += __shfl_xor(s, 32);
+            } else {
+                s = dzs_l[ut * 32 + jl];               // the column sums over all NR rows (in LDS since the prologue)
+            }
             if (hi == 0) {
                 const int h = ut * 32 + jl;
                 float wv = b1[h], mv = m_b1[h], vv = v_b1[h];
@@ -338,11 +361,15 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 
     float* Tw0 = Tt + w * UPW * 32 * TP;
     float* ssw = ssl + w * 64;
-    const bool row_next_ok = chain && jl < n_b_next;
-
-    f32x16 facc[UPW];
+    bool row_next_ok[RB];
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) facc[u] = f32x16{0};
+    for (int rb = 0; rb < RB; ++rb) row_next_ok[rb] = chain && 32 * rb + jl < n_b_next;
+
+    f32x16 facc[UPW][RB];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) facc[u][rb] = f32x16{0};
     float pg_acc = 0.f, pb_acc = 0.f;     // this wave's (dgamma | dbeta) partial over the sub-steps of a k-tile
 
     // Vector-memory operations of one sub-step, in program order (the hand-counted wait depends on it):
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         float* Tw = Tw0 + SUB * 32 * TP;
         float dzs[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dzs[r] = NHT == 8 ? dzs_r[r] : dzs_l[ut * 32 + rowmap(r, hi)];
+        for (int r = 0; r < 16; ++r) dzs[r] = DZS_REG ? dzs_r[r] : dzs_l[ut * 32 + rowmap(r, hi)];
         const int ktv = ktile(T, kq);
         // false only for the missing slots of a short last super-tile (wave-uniform); a workgroup that owns whole k-tiles
         // (UPW > 1 implies KTW == 1) has none
@@ -366,15 +393,20 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         const int kt = valid ? ktv : 0;
         const int k = kt * KT + jl;
         // this tile's small operands from LDS
-        const float* smc = sm + (par * KTW + kq) * CH_SM;
+        const float* smc = sm + (par * KTW + kq) * SMF;
+        const float* smf = smc + FO;             // the float section (offsets as for one row block)
         const uint8_t* xt = reinterpret_cast<const uint8_t*>(smc);
-        const u32x4 xp = *reinterpret_cast<const u32x4*>(xt + jl * 32 + hi * 16);      // 16 rows of SNP jl, packed
-        auto xv = [&](int r) { return (float)((xp[r >> 2] >> (8 * (r & 3))) & 255u); };
-        const float mu = smc[576 + jl], rs = smc[608 + jl];
-        const float gam = smc[640 + jl], bet = smc[672 + jl];          // gamma_k, beta_k before this step's update
-        float pv = smc[640 + lane], pm = smc[704 + lane], pvv = smc[768 + lane];
-        float nmu = smc[832 + jl], nvar = smc[864 + jl];
-        const u32x4 xr = *reinterpret_cast<const u32x4*>(smc + 256 + jl * 8 + 4 * hi);
+        u32x4 xp[RB];                            // 16 rows of SNP jl per row block, packed
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xp[rb] = *reinterpret_cast<const u32x4*>(xt + jl * NR + rb * 32 + hi * 16);
+        auto xv = [&](int rb, int r) { return (float)((xp[rb][r >> 2] >> (8 * (r & 3))) & 255u); };
+        const float mu = smf[576 + jl], rs = smf[608 + jl];
+        const float gam = smf[640 + jl], bet = smf[672 + jl];          // gamma_k, beta_k before this step's update
+        float pv = smf[640 + lane], pm = smf[704 + lane], pvv = smf[768 + lane];
+        float nmu = smf[832 + jl], nvar = smf[864 + jl];
+        u32x4 xr[RB];                            // next minibatch: row 32 rb + jl, SNPs 16 hi .. 16 hi + 15
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xr[rb] = *reinterpret_cast<const u32x4*>(smc + 256 * RB + (rb * 32 + jl) * 8 + 4 * hi);
         // ONE wait per iteration, right after the next unit's 12 loads (always 12: dummies on the last tile): "at most 12
         // outstanding" proves every older load landed -- this unit (requested an iteration ago) and the next tile's small
         // operands ld0..2 (requested at the end of the previous iteration).
@@ -389,7 +421,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         //   sum_b dxhat[b][k]          = sum_h W[h][k] dzsum[h]                      (this wave's 32 units; old W)
         f32x16 g = {0};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) g = mfma32(dzl[rowmap(s, hi) * PZ + ut * 32 + jl], (xv(s) - mu) * rs, g);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                g = mfma32(dzl[(32 * rb + rowmap(s, hi)) * PZ + ut * 32 + jl], (xv(rb, s) - mu) * rs, g);
         {
             float pg = 0.f, pb = 0.f;
 #pragma unroll
@@ -470,14 +505,20 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             for (int j = 0; j < 4; ++j) {
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssw + 16 * hi + 4 * j);
                 const f32x4 h4 = *reinterpret_cast<const f32x4*>(ssw + 32 + 16 * hi + 4 * j);
-                const uint32_t xw = xr[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float xb = (float)((xw >> (8 * e)) & 255u);
-                    const float a = row_next_ok ? fmaf(xb, s4[e], h4[e]) : 0.f;   // rows beyond the next minibatch: staged from row 0, unused
+                    float a[RB];
 #pragma unroll
-                    for (int u = 0; u < UPW; ++u)
-                        facc[u] = mfma32(a, Tw0[(u * 32 + 16 * hi + 4 * j + e) * TP + jl], facc[u]);
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const float xb = (float)((xr[rb][j] >> (8 * e)) & 255u);
+                        a[rb] = row_next_ok[rb] ? fmaf(xb, s4[e], h4[e]) : 0.f;   // rows beyond the next minibatch: staged from row 0, unused
+                    }
+#pragma unroll
+                    for (int u = 0; u < UPW; ++u) {
+                        const float wt = Tw0[(u * 32 + 16 * hi + 4 * j + e) * TP + jl];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) facc[u][rb] = mfma32(a[rb], wt, facc[u][rb]);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -509,11 +550,14 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     if (chain) {
         // D[i = row b][j = unit]: lane holds unit w*32 + jl, rows rowmap(r, hi) -- the layout l1_reduce_kernel sums
         // (one partial group per k-tile slot of this workgroup: group g * KTW + slot)
-        float* pout = partial_out + ((int64_t)blockIdx.x * KTW + kq) * 32 * Hp;
+        float* pout = partial_out + ((int64_t)blockIdx.x * KTW + kq) * NR * Hp;
 #pragma unroll
         for (int u = 0; u < UPW; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pout[rowmap(r, hi) * Hp + (ut0 + WPS * u) * 32 + jl] = facc[u][r];
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    pout[(32 * rb + rowmap(r, hi)) * Hp + (ut0 + WPS * u) * 32 + jl] = facc[u][rb][r];
     }
 }
 
@@ -528,12 +572,19 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
                                           float* m_beta, float* v_beta, float* b1, float* m_b1, float* v_b1,
                                           const float* alpha_tab, int alpha_tab_len, const float* lr, const int* t_base,
                                           int t_off, int grid, float* partial, int64_t partial_floats,
-                                          const loc_tuning* tune, const loc_dw_tail_args* tail, void* stream) {
+                                          const loc_tuning* tune, const loc_dw_tail_args* tail, int rb, void* stream) {
+    // rb = 32-row blocks the kernel is built for (1, or 2 for --batch_size 33..64 at width 256): fixed for a fit, because
+    // the partial sums it leaves are [group][32 rb][Hp]
+    if (rb < 1 || rb > 2 || (rb == 2 && d->Hp != 256)) {
+        loc_set_error("loc_l1_backward_adam_chain: %d row blocks at width %d (two need width 256)", rb, d->Hp);
+        return -1;
+    }
+    const int max_rows = LOC_ROWS * rb;
     if (!loc_l1_chain_supported(d->Hp)) { loc_set_error("loc_l1_backward_adam_chain: width must pad to 64, 128, 256 or 512 (got %d)", d->Hp); return -1; }
-    if (n_b < 1 || n_b > LOC_ROWS) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..32", n_b); return -1; }
-    if (rows_next && (n_b_next < 1 || n_b_next > LOC_ROWS || !bn_next_stats)) {
-        loc_set_error("loc_l1_backward_adam_chain: the next minibatch needs 1..32 rows (got %d) and its batch statistics",
-                      n_b_next);
+    if (n_b < 1 || n_b > max_rows) { loc_set_error("loc_l1_backward_adam_chain: n_b=%d out of 1..%d", n_b, max_rows); return -1; }
+    if (rows_next && (n_b_next < 1 || n_b_next > max_rows || !bn_next_stats)) {
+        loc_set_error("loc_l1_backward_adam_chain: the next minibatch needs 1..%d rows (got %d) and its batch statistics",
+                      max_rows, n_b_next);
         return -1;
     }
     if ((x_pitch % 16) != 0 || ((uintptr_t)X % 16) != 0) {
@@ -553,11 +604,11 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
     const int nkt = d->Kp / KT, n_super = (nkt + ktw - 1) / ktw;
     if (grid < 1) grid = 1;
     if (grid > n_super) grid = n_super;
-    if (rows_next && (int64_t)grid * ktw * 32 * d->Hp > partial_floats) {
+    if (rows_next && (int64_t)grid * ktw * max_rows * d->Hp > partial_floats) {
         loc_set_error("loc_l1_backward_adam_chain: partial buffer too small for %d workgroups x %d groups", grid, ktw);
         return -1;
     }
-    const size_t lds = ch_lds_floats(nht) * sizeof(float);
+    const size_t lds = ch_lds_floats(nht, rb) * sizeof(float);
     // the step's hidden-layer / head Adam tail as trailing workgroups: (L - 1) * 64 weight tiles + the head block
     loc_dw_tail_args ta = {};
     int n_tail = 0;
@@ -567,18 +618,24 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
         n_tail = (tail->L - 1) * nht * nht + 1;
     }
     const int ntm = !tune || tune->l1b_nt_mask == 0 ? 13 : (tune->l1b_nt_mask < 0 ? 0 : tune->l1b_nt_mask);
-#define LAUNCH_CHAIN_N(M, N)                                                                                       \
+#define LAUNCH_CHAIN_NR(M, N, R)                                                                                   \
     {                                                                                                              \
-        LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M, N>), lds);                                                     \
-        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M, N>), dim3(grid + n_tail), dim3(512), lds, (hipStream_t)stream, X, \
+        LOC_ENSURE_LDS((l1_bwd_adam_chain_kernel<M, N, R>), lds);                                                  \
+        hipLaunchKernelGGL((l1_bwd_adam_chain_kernel<M, N, R>), dim3(grid + n_tail), dim3(512), lds, (hipStream_t)stream, X, \
                            x_pitch, rows, n_b, rows_next, n_b_next, d->K, d->Kp, bn4, bn_next_stats, dz1, w1s, m1s, v1s, \
                            gamma, beta, m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, \
                            t_base, t_off, partial, n_tail, ta);                                                    \
     }
+#define LAUNCH_CHAIN_N(M, N) LAUNCH_CHAIN_NR(M, N, 1)
 #define LAUNCH_CHAIN(M)                                                                                            \
     {                                                                                                              \
         if (nht == 16) LAUNCH_CHAIN_N(M, 16) else if (nht == 8) LAUNCH_CHAIN_N(M, 8)                               \
         else if (nht == 4) LAUNCH_CHAIN_N(M, 4) else LAUNCH_CHAIN_N(M, 2)                                          \
+    }
+    if (rb == 2) {                        // two row blocks: width 256, default cache policy
+        LAUNCH_CHAIN_NR(13, 8, 2)
+        LOC_CHECK_LAUNCH();
+        return 0;
     }
     if (nht != 8) {                       // the cache-policy measurement switches exist for the default width only
         LAUNCH_CHAIN(13)
@@ -591,6 +648,7 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
         case 15: LAUNCH_CHAIN_N(15, 8) break;
         default: LAUNCH_CHAIN_N(13, 8) break;
     }
+#undef LAUNCH_CHAIN_NR
 #undef LAUNCH_CHAIN_N
 #undef LAUNCH_CHAIN
     LOC_CHECK_LAUNCH();
@@ -607,5 +665,5 @@ extern "C" int loc_l1_backward_adam_chain(const uint8_t* X, int64_t x_pitch, con
                                           const loc_tuning* tune, void* stream) {
     return l1_chain_launch(X, x_pitch, rows, n_b, rows_next, n_b_next, d, bn4, bn_next_stats, dz1, w1s, m1s, v1s, gamma, beta,
                            m_gamma, v_gamma, m_beta, v_beta, b1, m_b1, v_b1, alpha_tab, alpha_tab_len, lr, t_base, t_off,
-                           grid, partial, partial_floats, tune, nullptr, stream);
+                           grid, partial, partial_floats, tune, nullptr, 1, stream);
 }

@@ -24,7 +24,7 @@ int l1_chain_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int 
                     float* v1s, float* gamma, float* beta, float* m_gamma, float* v_gamma, float* m_beta, float* v_beta,
                     float* b1, float* m_b1, float* v_b1, const float* alpha_tab, int alpha_tab_len, const float* lr,
                     const int* t_base, int t_off, int grid, float* partial, int64_t partial_floats, const loc_tuning* tune,
-                    const loc_dw_tail_args* tail, void* stream);
+                    const loc_dw_tail_args* tail, int rb, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // Everything that reduces over the batch rows, for all hidden layers at once.

@@ -154,7 +154,9 @@ class LocatorNet:
                 if self.ws_predict is not None:
                     self.ws_predict = torch.empty_like(self.ws)
         else:
-            self.slot_rows = LOC_BATCH_SLOT if batch_size > LOC_ROWS else LOC_ROWS
+            # 33..64 rows: 64 tells the library that steps of two 32-row blocks may be chained (loc_train_chain_supported);
+            # the scratch layout is the 128-row one either way
+            self.slot_rows = LOC_ROWS if batch_size <= LOC_ROWS else (64 if batch_size <= 64 else LOC_BATCH_SLOT)
         self._net = None
         return self.slot_rows
 
@@ -311,7 +313,8 @@ class LocatorNet:
 
     def chain_supported(self):
         """True when consecutive steps of an epoch may be chained (loc_train_step_chain: the layer-1 backward of step t
-        also produces the layer-1 forward of step t + 1): width padding to 256, nlayers >= 2, batch <= 32, Dropout not
+        also produces the layer-1 forward of step t + 1): width padding to 64 / 128 / 256 / 512, nlayers >= 2, batch <= 32 (<= 64 at
+        width 256), Dropout not
         on the BatchNorm output."""
         net = self._net or self.cnet()
         return bool(self.lib.loc_train_chain_supported(C.byref(net)))

@@ -112,7 +112,8 @@ def test_train_chain_supported_is_decided_by_shape_alone():
     assert ok(width=512) and ok(width=481)                                         # ... and 16 (two per wave)
     assert not ok(width=224) and not ok(width=257) and not ok(width=32) and not ok(width=513) and not ok(width=1024)
     assert not ok(nlayers=1) and ok(nlayers=1, drop=0.0) is False
-    assert not ok(slot_rows=128)                                     # --batch_size > 32
+    assert not ok(slot_rows=128)                                     # --batch_size > 64
+    assert ok(slot_rows=64) and not ok(slot_rows=64, width=128) and not ok(slot_rows=64, width=512)   # 33..64: two row blocks, width 256 only
     assert not ok(wht=None)                                          # no fused hidden stack
     assert not ok(pitch=100008)                                      # rows not 16-byte aligned
     assert ok(K=4194240) and not ok(K=4194304)                       # Kp * 1024 < 2^32

@@ -33,9 +33,9 @@ def _kernels(source, pattern):
     return res
 
 
-def _kernel_asm(nht=8):
-    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13ELi%dEE" % nht)
-    assert len(ks) == 1, f"kernel instantiation <13, {nht}> not found in the assembly"
+def _kernel_asm(nht=8, rb=1):
+    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13ELi%dELi%dEE" % (nht, rb))
+    assert len(ks) == 1, f"kernel instantiation <13, {nht}, {rb}> not found in the assembly"
     return next(iter(ks.values()))
 
 
@@ -139,13 +139,13 @@ def _walk(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("nht", [16, 8, 4, 2])
-def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_counted_wait(nht):
+@pytest.mark.parametrize("nht,rb", [(16, 1), (8, 1), (4, 1), (2, 1), (8, 2)])
+def test_no_instruction_touches_an_untracked_load_destination_before_the_hand_counted_wait(nht, rb):
     """Every width the chained kernel is built for (round 4: 16, 8, 4, 2 unit tiles = widths padding to 512, 256, 128, 64; a
     wave then carries 1, 1, 2 or 4 loader roles of 3 small loads each; with 16 unit tiles the loop body holds four sub-steps
     of 12 loads, two of them followed by the small loads)."""
-    small = 3 * ((7 * max(8 // nht, 1) + 7) // 8)
-    prog, lo, hi, n_loads, n_waits = _walk(_kernel_asm(nht))
+    small = 3 * (((4 * rb + 3) * max(8 // nht, 1) + 7) // 8)      # (8, 2): two row blocks per minibatch, 11 loader roles
+    prog, lo, hi, n_loads, n_waits = _walk(_kernel_asm(nht, rb))
     assert sum(1 for k, _, _ in prog[lo:hi + 1] if k == "aload") >= 2 * (12 + small), f"main loop with its 2 x (12 + {small}) loads not found"
     assert n_loads >= 3 * (12 + small) and n_waits >= 4
     # the loop's waits are the pipelined ones, and the loop is drained before the epilogue reuses registers

@@ -41,16 +41,16 @@ def _assert_same_fit(p0, p1, m0, m1, v0, v1):
     assert err["mov_mean"] == 0.0 and err["mov_var"] == 0.0
 
 
-def _run_epochs(x, y, p, tr, va, perms, chain, drop_p, use_graph, seed=5):
+def _run_epochs(x, y, p, tr, va, perms, chain, drop_p, use_graph, seed=5, batch=32):
     from locator_amd.train import EpochRunner
     net = build_net(x, y, p, drop_p=drop_p, seed=seed)
-    runner = EpochRunner(net, tr, va, 32, use_graph=use_graph, chain=chain)
+    runner = EpochRunner(net, tr, va, batch, use_graph=use_graph, chain=chain)
     assert runner.chain == bool(chain)
     hist, masks = [], []
     for perm in perms:
         hist.append(runner.run_epoch(perm))
         if runner.masks is not None:
-            masks.append(runner.masks.cpu().numpy().reshape(runner.steps, 32, net.d.Hp).copy())
+            masks.append(runner.masks.cpu().numpy().reshape(runner.steps, runner.slot_rows, net.d.Hp).copy())
     _sync()
     m, v = net.export_adam()
     return net, hist, net.export_params(), m, v, masks
@@ -160,7 +160,10 @@ def test_chain_is_refused_where_it_does_not_apply():
     x, y, p, rng = make_problem(80, 500, 256, 4, seed=1)
     net = build_net(x, y, p)
     assert net.chain_supported()
-    assert not EpochRunner(net, np.arange(60), np.arange(60, 80), 64).chain      # --batch_size > 32
+    assert EpochRunner(net, np.arange(60), np.arange(60, 80), 64).chain          # --batch_size 33..64 at width 256: two row blocks
+    assert not EpochRunner(net, np.arange(60), np.arange(60, 80), 65).chain      # --batch_size > 64
+    x5, y5, p5, _ = make_problem(80, 500, 128, 4, seed=1)
+    assert not EpochRunner(build_net(x5, y5, p5), np.arange(60), np.arange(60, 80), 64).chain   # two row blocks: width 256 only
     loss = torch.zeros(1, device="cuda")
     rows = torch.arange(32, dtype=torch.int32, device="cuda")
     net.set_batch(32)
@@ -180,6 +183,45 @@ def test_chained_epochs_equal_unchained_epochs_at_the_baseline_width_of_snps_nar
     _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, 0.25, True)
     assert maxerr(h0, h1) < 2e-5, (h0, h1)
     _assert_same_fit(p0, p1, m0, m1, v0, v1)
+
+
+@pytest.mark.parametrize("K,nlayers,n_train,batch,drop_p", [
+    (5000, 4, 150, 64, 0.25),       # fewer k-tiles than workgroups; minibatches of 64, 64, 22 rows (the last uses ONE row block)
+    (40010, 10, 170, 48, 0.25),     # several k-tiles per workgroup; 48, 48, 48, 26
+    (3000, 4, 100, 33, 0.0),        # 33 rows: the second block carries one row; last minibatch of 1 row
+    (100000, 10, 192, 64, 0.25),    # the baseline width of SNPs, three full minibatches
+])
+def test_chained_epochs_of_two_row_blocks_equal_unchained_epochs(K, nlayers, n_train, batch, drop_p):
+    """--batch_size 33..64 at width 256 (round 4, late): l1_bwd_adam_chain_kernel<13, 8, 2> - dZ of 64 rows in LDS, two
+    fp32 MFMA chains of 16 per unit each way, the hidden-layer tail with a run-time block count - against the unchained
+    schedule of the same batch size (large-M bf16x3 forward + row-block backward + tail launch), graph replay and eager."""
+    x, y, p, rng = make_problem(n_train + 20, K, 256, nlayers, seed=K % 97 + batch)
+    tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
+    perms = [np.random.default_rng(50 + e).permutation(n_train) for e in range(3)]
+    _, h0, p0, m0, v0, _ = _run_epochs(x, y, p, tr, va, perms, False, drop_p, True, batch=batch)
+    _, h1, p1, m1, v1, _ = _run_epochs(x, y, p, tr, va, perms, True, drop_p, True, batch=batch)
+    _, h2, p2, m2, v2, _ = _run_epochs(x, y, p, tr, va, perms, True, drop_p, False, batch=batch)
+    assert maxerr(h0, h1) < 2e-5, (h0, h1)
+    _assert_same_fit(p0, p1, m0, m1, v0, v1)
+    assert h1 == h2 and params_err(p1, p2) == {k: 0.0 for k in params_err(p1, p2)}      # graph replay = eager, bit for bit
+    assert np.abs(p1["W"][0] - p["W"][0]).max() > 1e-4
+
+
+def test_chained_epochs_of_two_row_blocks_match_the_oracle_fit():
+    """Chained 48-row steps against oracle.fit with the same permutations and the device's dropout masks (3 epochs x 3
+    steps, last minibatch of 4 rows)."""
+    K, nlayers, width, batch = 2500, 4, 256, 48
+    x, y, p, rng = make_problem(130, K, width, nlayers, seed=34)
+    tr, va = np.arange(0, 100), np.arange(100, 120)
+    perms = [np.random.default_rng(200 + e).permutation(100) for e in range(3)]
+    net, hist, pg, _, _, masks = _run_epochs(x, y, p, tr, va, perms, True, 0.25, True, seed=11, batch=batch)
+    pref = O.copy_params(p)
+    href, _ = O.fit(pref, x[tr], y[tr], x[va], y[va], batch_size=batch, max_epochs=3, patience=100, drop_p=0.25,
+                    perm_fn=lambda e: perms[e], mask_fn=lambda e, s, nb: masks[e][s, :nb, :width])
+    assert maxerr([h[0] for h in hist], href["loss"]) < 5e-4
+    assert maxerr([h[1] for h in hist], href["val_loss"]) < 5e-4
+    err = params_err(pg, pref)
+    assert max(err.values()) < 2e-4, err
 
 
 @pytest.mark.parametrize("K,n_b,n_b_next,width", [(4000, 32, 32, 256), (4000, 17, 5, 256), (9990, 32, 32, 256),
@@ -323,11 +365,11 @@ def test_hand_counted_wait_of_the_chained_kernel_equals_its_drained_build_bit_fo
     assert out[0] == out[1], out
 
 
-def _run_xchain(x, y, p, tr, va, perms, xchain, use_graph, width_seed=5):
+def _run_xchain(x, y, p, tr, va, perms, xchain, use_graph, width_seed=5, batch=32):
     """Epochs through EpochRunner with (or without) the cross-epoch hand-over: epoch e is given epoch e + 1's permutation."""
     from locator_amd.train import EpochRunner
     net = build_net(x, y, p, drop_p=0.25, seed=width_seed)
-    runner = EpochRunner(net, tr, va, 32, use_graph=use_graph, chain=True, xchain=xchain)
+    runner = EpochRunner(net, tr, va, batch, use_graph=use_graph, chain=True, xchain=xchain)
     assert runner.xchain == xchain
     hist = []
     for e, perm in enumerate(perms):
@@ -338,8 +380,9 @@ def _run_xchain(x, y, p, tr, va, perms, xchain, use_graph, width_seed=5):
     return net, hist, net.export_params(), m, v
 
 
-@pytest.mark.parametrize("width,K,n_train", [(512, 30010, 96), (256, 40010, 96), (256, 5000, 74), (128, 20000, 96), (64, 9000, 70)])
-def test_cross_epoch_chaining_equals_the_per_epoch_schedule(width, K, n_train):
+@pytest.mark.parametrize("width,K,n_train,batch", [(512, 30010, 96, 32), (256, 40010, 96, 32), (256, 5000, 74, 32), (128, 20000, 96, 32),
+                                                   (64, 9000, 70, 32), (256, 20000, 150, 64)])
+def test_cross_epoch_chaining_equals_the_per_epoch_schedule(width, K, n_train, batch):
     """Round 4: the last step of an epoch also computes the first layer-1 forward of the next epoch (its rows and batch
     statistics are known an epoch early), so every epoch but the first starts from a hand-over instead of an unchained
     forward; the validation sweep in between works in a second workspace.  Five epochs (eager, eager, then one captured
@@ -348,9 +391,9 @@ def test_cross_epoch_chaining_equals_the_per_epoch_schedule(width, K, n_train):
     x, y, p, rng = make_problem(n_train + 20, K, width, 4, seed=K % 89)
     tr, va = np.arange(n_train), np.arange(n_train, n_train + 20)
     perms = [np.random.default_rng(17 + e).permutation(n_train) for e in range(5)]
-    _, h0, p0, m0, v0 = _run_xchain(x, y, p, tr, va, perms, False, True)
-    _, h1, p1, m1, v1 = _run_xchain(x, y, p, tr, va, perms, True, True)
+    _, h0, p0, m0, v0 = _run_xchain(x, y, p, tr, va, perms, False, True, batch=batch)
+    _, h1, p1, m1, v1 = _run_xchain(x, y, p, tr, va, perms, True, True, batch=batch)
     assert maxerr(h0, h1) < 5e-5, (h0, h1)
     _assert_same_fit(p0, p1, m0, m1, v0, v1)
-    _, h2, p2, m2, v2 = _run_xchain(x, y, p, tr, va, perms, True, False)
+    _, h2, p2, m2, v2 = _run_xchain(x, y, p, tr, va, perms, True, False, batch=batch)
     assert h1 == h2 and max(params_err(p1, p2).values()) == 0.0
