@@ -89,7 +89,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(K, H, n, kernel):
+def measured_traffic(K, H, n, kernel, batch=32):
     """PMC bytes per launch of `kernel` (name prefix) from the committed profile, or (None, why) when it does not describe the
     kernel that is running now."""
     path = os.path.join(ROOT, TRAFFIC_PROFILE)
@@ -97,7 +97,7 @@ def measured_traffic(K, H, n, kernel):
         pm = json.load(open(path))
     except Exception:
         return None, f"{TRAFFIC_PROFILE} missing"
-    if pm.get("workload") != {"K": K, "H": H, "n": n}:
+    if pm.get("workload") != {"K": K, "H": H, "n": n} or batch != 32:       # (the passes run the default --batch_size)
         return None, f"{TRAFFIC_PROFILE} is for another workload"
     if pm.get("kernel_sources_sha256_16") != kernel_sources_sha():
         return None, f"{TRAFFIC_PROFILE} was taken on other kernel sources (re-run tools/pmc_traffic.sh)"
@@ -569,7 +569,7 @@ def main():
         t_mean = float(np.mean(ms)) * 1e-3
         achieved = float(np.mean(by)) / t_mean / 1e9
         kname = "l1_bwd_adam_chain_kernel" if f0.runner.chain else "l1_bwd_adam_kernel<%d" % ((H + 31) // 32)
-        traffic, traffic_source = measured_traffic(K, H, n, kname)
+        traffic, traffic_source = measured_traffic(K, H, n, kname, args.batch)
         roof = {"bound": "hbm", "kernel": kname.split("<")[0], "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source, "bytes_per_launch": int(np.mean(by)),

@@ -46,6 +46,7 @@ bash tools/config1_timeline.sh ${TAG}sync --sync >> $O/config1_timeline.log 2>&1
 python3 tools/predict_timeline.py --mode auto > $O/${TAG}_predict_timeline.jsonl 2>/dev/null
 for w in 512 128 64; do python3 bench.py --steps 20 --warmup 4 --width $w --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_width$w.json 2>/dev/null; python3 bench.py --steps 20 --warmup 4 --width $w --no-chain --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_width${w}_unchained.json 2>/dev/null; done
 for b in 64 128; do python3 bench.py --steps 20 --warmup 4 --batch $b --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_batch$b.json 2>/dev/null; done
+python3 bench.py --steps 20 --warmup 4 --batch 64 --no-chain --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_batch64_unchained.json 2>/dev/null
 python3 bench.py --steps 40 --warmup 5 --sync-epochs --no-cpu-baseline --no-l1-gemm > $O/${TAG}_bench_sync_epochs.json 2>/dev/null
 tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
