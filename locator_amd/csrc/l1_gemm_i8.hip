@@ -108,66 +108,70 @@ __global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __
                                                               const float* __restrict__ sumabs_part, int nparts, int K, int H,
                                                               float* __restrict__ guard) {
     __shared__ __attribute__((aligned(16))) float R[G8_HP];
-    __shared__ float qs[4][G8_HP];
-    // 1024 threads: thread (q, n) adds the workgroup shares b = q, q + 4, ... of unit n, all at once (a single
-    // wave per unit walking 512 strided shares one after the other took 127 us); the four
-    // quarters, then the units' statistics, are combined in a fixed order
+    __shared__ __attribute__((aligned(16))) float qs[16][G8_HP];
+    // 1024 threads: thread (q, n4) adds the workgroup shares b = q, q + 16, ... of the four units 4 n4 .. 4 n4 + 3, all at
+    // once, as 16-byte loads: the shares were written by workgroups on every XCD, so each load is a trip to memory, and a
+    // compute unit retires a 4-byte-per-lane load instruction no faster than a 16-byte one (1,024 of them took 10 of this
+    // kernel's 15 us; a single wave per unit walking 512 strided shares one after the other: 127 us).  The sixteen
+    // partial sums of a unit, then the units' statistics, are combined in a fixed order.
     {
-        const int n = threadIdx.x & (G8_HP - 1), q = threadIdx.x >> 8;
-        // the shares were written by workgroups on every XCD, so each load is a trip to memory: all of a thread's loads
-        // (nparts <= 256: at most 64) are issued at once, then added in a fixed order
-        float a[64];
+        const int n4 = threadIdx.x & 63, q = threadIdx.x >> 6;
+        f32x4 a[16];
 #pragma unroll
-        for (int e = 0; e < 64; ++e) {
-            const int b = q + 4 * e;
-            a[e] = b < nparts ? sumabs_part[(int64_t)b * G8_HP + n] : 0.f;
+        for (int e = 0; e < 16; ++e) {
+            const int b = q + 16 * e;
+            a[e] = b < nparts ? *reinterpret_cast<const f32x4*>(sumabs_part + (int64_t)b * G8_HP + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int w2 = 32; w2 > 0; w2 >>= 1)
+        for (int w2 = 8; w2 > 0; w2 >>= 1)
 #pragma unroll
-            for (int e = 0; e < w2; ++e) a[e] += a[e + w2];
-        qs[q][n] = a[0];
+            for (int e = 0; e < w2; ++e) a[e] = a[e] + a[e + w2];
+        *reinterpret_cast<f32x4*>(&qs[q][4 * n4]) = a[0];
     }
     __syncthreads();
     // (every thread reaches the barriers below; the statistics are the first 256 threads' work)
     const int n = threadIdx.x & (G8_HP - 1);
     const bool first = threadIdx.x < G8_HP;
-    const float ss = (qs[0][n] + qs[1][n]) + (qs[2][n] + qs[3][n]);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ss += qs[q][n];
     const float mx = bitsf(colmax[n]);
     const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
     const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
     if (first) R[n] = r;
     __syncthreads();
-    // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
-    // (sixteen values per round of LDS reads: one value per read, one read at a time, was most of this kernel's 16 us)
-    int rank = 0;
-    if (first) {               // 256 x 256 comparisons: by the four waves that need them, not by all sixteen
-        const f32x4* R4 = reinterpret_cast<const f32x4*>(R);
-#pragma unroll 1
-        for (int j0 = 0; j0 < G8_HP; j0 += 16) {
-            f32x4 v[4];
+    // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries.  The
+    // 256 x 256 comparisons are most of this kernel's arithmetic: every thread takes a quarter of the candidates of its unit
+    // (thread (p, n): entries 64 p .. 64 p + 63), the four partial counts meet in LDS
+    __shared__ int rk[4][G8_HP];
+    {
+        const int p = threadIdx.x >> 8;
+        const f32x4* R4 = reinterpret_cast<const f32x4*>(R) + 16 * p;
+        int cnt = 0;
+#pragma unroll 4
+        for (int j4 = 0; j4 < 16; ++j4) {
+            const f32x4 v = R4[j4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = R4[j0 / 4 + e];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float x = v[e >> 2][e & 3];
-                const int j = j0 + e;
-                rank += (j < H && (x < r || (x == r && j < n))) ? 1 : 0;
+            for (int e = 0; e < 4; ++e) {
+                const int j = 64 * p + 4 * j4 + e;
+                cnt += (j < H && (v[e] < r || (v[e] == r && j < n))) ? 1 : 0;
             }
         }
+        rk[p][n] = cnt;
     }
-    __shared__ float red[G8_HP];
-    if (first) red[n] = r;
     __syncthreads();
-    for (int o = G8_HP / 2; o > 0; o >>= 1) {
-        if (first && n < o) red[n] = fmaxf(red[n], red[n + o]);
-        __syncthreads();
-    }
+    const int rank = (rk[0][n] + rk[1][n]) + (rk[2][n] + rk[3][n]);
+    // the largest R: inside each of the first four waves by lane exchanges, then four values through LDS
+    __shared__ float red[4];
+    float wmax = r;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (first && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
     __shared__ float s_med;
     if (first && n < H && rank == (H - 1) / 2) s_med = r;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float rmed = s_med, rmax = red[0];
+        const float rmed = s_med, rmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         guard[0] = rmed;
         guard[1] = rmax;
         const float exact = rmax <= LOC_GUARD_EXACT_MAX ? 3.f : -1.f;
