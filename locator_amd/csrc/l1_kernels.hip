@@ -96,48 +96,6 @@ __global__ __launch_bounds__(128) void bn_epoch_stats_kernel(const uint8_t* __re
     *reinterpret_cast<f32x4*>(o + Kp + k0) = var;
 }
 
-// The same with 16 SNPs per thread (one 16-byte load per row; rows 16-byte aligned): a compute unit retires a 4-byte-per-lane
-// load instruction no faster than a 16-byte one, and this kernel is nothing but loads (round 4, late: 21.8 -> 14 us at
-// 810 x 100,000).  Integer sums, the same expressions per SNP: the statistics are the same bits.
-__global__ __launch_bounds__(128) void bn_epoch_stats16_kernel(const uint8_t* __restrict__ X, int64_t pitch,
-                                                               const int32_t* __restrict__ rows_all, int batch,
-                                                               int n_last, int n_steps, int K, int Kp,
-                                                               float* __restrict__ stats_ep) {
-    const int k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    const int step = blockIdx.y;
-    if (k0 >= Kp) return;
-    const int n_b = step == n_steps - 1 ? n_last : batch;
-    const int32_t* rows = rows_all + (int64_t)step * batch;
-    int s[16], ss[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) { s[c] = 0; ss[c] = 0; }
-#pragma unroll 4
-    for (int b = 0; b < n_b; ++b) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(X + (int64_t)rows[b] * pitch + k0);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int x = (v[c >> 2] >> (8 * (c & 3))) & 255;
-            s[c] += x;
-            ss[c] += x * x;
-        }
-    }
-    float* o = stats_ep + (int64_t)step * 2 * Kp;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 mu = {0, 0, 0, 0}, var = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = 4 * q + c;
-            if (k0 + e < K) {
-                mu[c] = (float)s[e] / (float)n_b;
-                var[c] = (float)((int64_t)n_b * ss[e] - (int64_t)s[e] * s[e]) / ((float)n_b * (float)n_b);
-            }
-        }
-        *reinterpret_cast<f32x4*>(o + k0 + 4 * q) = mu;
-        *reinterpret_cast<f32x4*>(o + Kp + k0 + 4 * q) = var;
-    }
-}
-
 // Moving-statistics recurrence over the epoch's steps (same order and arithmetic as the per-step
 // update) and bn4 = [scale|shift|mean|rstd] for step 0 from the current gamma/beta.
 __global__ void bn_epoch_finish_kernel(int K, int Kp, int n_steps, const float* __restrict__ stats_ep,
@@ -958,16 +916,6 @@ extern "C" int loc_bn_batch_stats(const uint8_t* X, int64_t x_pitch, const int32
     return 0;
 }
 
-static void bn_epoch_stats_launch(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last, int n_steps,
-                                  int K, int Kp, float* stats_ep, void* stream) {
-    if ((x_pitch % 16) == 0 && ((uintptr_t)X % 16) == 0 && (Kp % 16) == 0)
-        hipLaunchKernelGGL(bn_epoch_stats16_kernel, dim3((Kp / 16 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
-                           X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
-    else
-        hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
-                           X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
-}
-
 extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32_t* rows_all, int batch, int n_last,
                                   int n_steps, int K, int Kp, const float* gamma, const float* beta,
                                   float* mov_mean, float* mov_var, float* stats_ep, float* bn4, void* stream) {
@@ -975,7 +923,8 @@ extern "C" int loc_bn_epoch_stats(const uint8_t* X, int64_t x_pitch, const int32
         loc_set_error("loc_bn_epoch_stats: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
         return -1;
     }
-    bn_epoch_stats_launch(X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep, stream);
+    hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
+                       X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
     LOC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_epoch_finish_kernel, dim3((Kp + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, Kp,
                        n_steps, stats_ep, gamma, beta, mov_mean, mov_var, bn4);
@@ -992,7 +941,8 @@ extern "C" int loc_bn_epoch_stats_only(const uint8_t* X, int64_t x_pitch, const 
         loc_set_error("loc_bn_epoch_stats_only: bad batch=%d n_last=%d n_steps=%d", batch, n_last, n_steps);
         return -1;
     }
-    bn_epoch_stats_launch(X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep, stream);
+    hipLaunchKernelGGL(bn_epoch_stats_kernel, dim3((Kp / 4 + 127) / 128, n_steps), dim3(128), 0, (hipStream_t)stream,
+                       X, x_pitch, rows_all, batch, n_last, n_steps, K, Kp, stats_ep);
     LOC_CHECK_LAUNCH();
     return 0;
 }
