@@ -29,11 +29,11 @@ The JSON line also carries
   cpu_baseline  the torch-CPU fp32 restatement of the same epochs (oracle/torch_cpu.py: "restated reference on CPU
                 (torch), not TensorFlow") on this box's physical cores, validation sweep included,
                 bounded to ~12 s; `numpy_port` = the single-threaded-Adam NumPy oracle step for comparison.
-  l1_gemm       (N=1) the large-M first-layer genotype GEMM (model.predict over all 1000 rows; 4096 rows of the same
-                matrix = the batched --jacknife; 4096 DISTINCT rows streaming from HBM) as a fraction of the dense
-                bf16-MFMA peak, for every predict mode the CLI ships - int8 x 3 digits (default, exact), int8 x 2
-                (fast), bf16 x 3 / 2 / 1 pieces - each with the tolerance its predictions are tested to, plus the
-                in-loop-conversion kernel used for few rows.
+  l1_gemm       (N=1) a dozen-number summary of the large-M first-layer genotype GEMM (model.predict) in the default
+                predict mode as a fraction of the dense bf16-MFMA peak (l1_gemm_summary).  The full mode x shape sweep
+                lives in tools/l1_gemm_sweep.py / --l1-gemm-full FILE and never enters the line.
+
+The line is the last thing printed, strict JSON, at most MAX_LINE_BYTES (format_line; tests/test_host.py).
 """
 import argparse
 import hashlib
@@ -104,216 +104,107 @@ def measured_traffic(K, H, n, kernel, batch=32):
     key = [k for k in pm["kernels"] if k.startswith(kernel)]
     if not key:
         return None, "kernel not in profile"
-    return int(pm["kernels"][key[0]]["traffic_bytes"]), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, sources {pm['kernel_sources_sha256_16']})"
+    return int(pm["kernels"][key[0]]["traffic_bytes"]), f"{TRAFFIC_PROFILE} (rocprofv3 --pmc passes, sources {pm['kernel_sources_sha256_16']})"
 
 
-def _time_graphed(fn, iters):
-    """Mean microseconds of fn() (which enqueues on the current stream), replayed from a captured HIP graph so host
-    launch overhead does not pad kernel time."""
-    import torch
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(g, stream=s):
-            for _ in range(iters):
-                fn()
-        g.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.synchronize()
-        e0.record(s)
-        g.replay()
-        e1.record(s)
-        s.synchronize()
-    torch.cuda.current_stream().wait_stream(s)
-    return e0.elapsed_time(e1) * 1e3 / iters
-
-
-def _time_burst(fn, n=3, idle_s=0.25):
-    """Mean microseconds of fn() over a short burst of n launches after the GPU sat idle: the matrix-pipe kernels clock
-    down within a few ms of back-to-back load (rocprofv3 trace: launch 1-12 of l1_gemm_kernel<3> 122 us, launch 20
-    154 us), and a predict issues ONE such launch per 4096 rows, not twenty."""
-    import torch
-    fn()
-    torch.cuda.synchronize()
-    best = None
-    for _ in range(3):
-        time.sleep(idle_s)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / n
-        best = us if best is None else min(best, us)
-    return best
-
-
-# Predict modes the CLI ships (locator_amd/locator.py --predict_mode / --predict_pieces) and the bar each one is held to
-# on the PREDICTIONS at this workload's K (tests/test_gpu_baseline_sizes.py::test_config2_predict_all_rows):
-PREDICT_MODE_INFO = {
-    "int8x3": "--predict_mode exact (and what the default takes when the dynamic-range guard refuses two planes): 24-bit fixed "
-              "point per weight, predictions 2e-5 absolute; tests/test_gpu_trained_predict.py: 8e-7 on converged fits",
-    "int8x2": "DEFAULT (--predict_mode auto) while the guard allows it (largest / typical scaled weight per unit: median <= 64, "
-              "worst <= 512; converged metric fit: 28 / 77): 16-bit fixed point per weight, predictions <= 1e-3 relative "
-              "(north_star bound), measured 5e-5 on the converged metric fit, 7e-5 on the reference's example fit "
-              "(tests/test_gpu_trained_predict.py); also --predict_mode fast (unconditional)",
-    "bf16x3": "--predict_pieces 3 (and the fallback for genotypes > 127): fp32-exact products, 2e-5 absolute",
-    "bf16x2": "--predict_pieces 2: predictions <= 1e-3 relative",
-    "bf16x1": "--predict_pieces 1: plain bf16 weights, predictions only within 2e-2 - OUTSIDE the north_star tolerance, "
-              "listed for reference, not a figure against the MFMA target",
-}
-
-
-def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
-    """The only large-M contraction on the path (model.predict / --jacknife, locator.py:414, :441, :683-747):
-    a1 = ELU(BN(x) W1 + b1) for M rows at once.  flops = 2*M*K*H counted ONCE, however many int8 digits or bf16 pieces
-    carry each fp32 weight; the denominator is the dense bf16-MFMA peak for every mode (int8 digits run on the i8 pipe
-    at twice the bf16 rate: 3 digits cost 1.5 bf16-MFMA equivalents per product, 2 digits 1).  Shapes: M = every row of
-    the matrix (model.predict over all samples); M = 4096 and M = 16384 (= LOC_PREDICT_CHUNK, what loc_predict launches at
-    a time) rows drawn from it (the batched --jacknife: nboots x n_pred perturbed rows of the same matrix in one predict, so
-    genotype lines repeat and come from L2 / MALL); M = 4096 and M = 16384
-    DISTINCT rows of a second synthetic matrix (every genotype byte streams from HBM once).  Per shape and mode: us =
-    GEMM + its reduction, mean of `iters` back-to-back launches replayed from a graph (the sustained, clocked-down
-    rate); us_prep = the once-per-predict weight conversion (not in us; frac_bf16_peak_incl_prep has it); burst_of_3 =
-    three launches from idle; `in_loop_conversion` = loc_l1_forward_rows, which converts inside the K loop (few rows)."""
+def l1_gemm_summary(net, n_matrix, iters=10):
+    """The large-M first-layer genotype GEMM (model.predict / --jacknife, locator.py:414, :441, :713-741) in the DEFAULT
+    predict mode (--predict_mode auto: int8 digit planes chosen by the dynamic-range guard) as a fraction of the dense
+    bf16-MFMA peak: flops = 2*M*K*H counted once however many planes carry a weight.  Three shapes: every row of the
+    matrix (M = n), 4096 and 16384 DISTINCT rows streaming from HBM, each from bytes and from the 2-bit packed copy the
+    predict keeps for >= 3072 rows; us_prep = the once-per-predict weight image build, `incl_prep` has it in the
+    denominator.  A dozen numbers; the full mode x shape sweep is tools/l1_gemm_sweep.py (--l1-gemm-full)."""
     import ctypes as C
 
     import torch
     from locator_amd import _lib
+    from tools.l1_gemm_sweep import _time_graphed, distinct_rows
     lib, d, lay = net.lib, net.d, net.lay
-    P = net.params.data_ptr()
-    dev = net.params.device
+    P, dev = net.params.data_ptr(), net.params.device
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = net.quant_guard()
+    digits = int(g[2])
+    out = {"mode": "int8x%d" % digits if digits > 0 else "bf16x3", "peak_tflops": BF16_PEAK_TFLOPS,
+           "guard_median": round(g[0], 1), "guard_max": round(g[1], 1)}
+    if digits <= 0 or not lib.loc_l1_gemm_i8_supported(d.Hp, digits):
+        return out
     bn4 = torch.zeros(4 * d.Kp, device=dev)
     _lib.check(lib.loc_bn_infer_scale_shift(d.K, d.Kp, P + 4 * lay.gamma, P + 4 * lay.beta, P + 4 * lay.mov_mean,
                                             P + 4 * lay.mov_var, bn4.data_ptr(), st()))
     partial = torch.empty(256 * 128 * d.Hp, device=dev)
+    image = torch.empty(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device=dev)
+    prep = lambda: _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, digits,
+                                                        image.data_ptr(), st()))
+    prep()
+    us_prep = _time_graphed(prep, 10)
+    out["us_prep"] = round(us_prep, 1)
+    frac = lambda fl, us: round(fl / us * 1e-6 / BF16_PEAK_TFLOPS, 4)
 
-    def shape(X, n_rows, n_src, in_loop=True):
+    def shape(X, n_rows, n_src, packed):
         rows = (torch.arange(n_rows, dtype=torch.int32, device=dev) % n_src).contiguous()
         a1 = torch.empty(((n_rows + 127) // 128 * 128, d.Hp), device=dev)
-        flops = 2.0 * n_rows * d.K * d.H
-        out = {"rows": n_rows, "distinct_rows": min(n_rows, n_src), "flops": flops}
+        fl = 2.0 * n_rows * d.K * d.H
+        run = lambda: _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n_rows, C.byref(d),
+                                                            image.data_ptr(), digits, 2, P + 4 * lay.b1, partial.data_ptr(),
+                                                            partial.numel(), a1.data_ptr(), 0, None, st()))
+        us = _time_graphed(run, iters)
+        r = {"us": round(us, 1), "frac": frac(fl, us), "incl_prep": frac(fl, us + us_prep)}
+        if packed:
+            X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
+            _lib.check(lib.loc_pack_genotypes_2bit(X.data_ptr(), X.stride(0), X.shape[0], d.Kp, X2.data_ptr(), X2.stride(0), st()))
+            runp = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr(), X2.stride(0), rows.data_ptr(), n_rows,
+                                                                        C.byref(d), image.data_ptr(), digits, P + 4 * lay.b1,
+                                                                        partial.data_ptr(), partial.numel(), a1.data_ptr(), 0,
+                                                                        None, st()))
+            usp = _time_graphed(runp, iters)
+            r["packed"] = {"us": round(usp, 1), "frac": frac(fl, usp), "incl_prep": frac(fl, usp + us_prep)}
+        return r
 
-        def rec(us, mfma_equiv, byts):
-            tf = flops / us * 1e-6
-            return {"us": round(us, 1), "tflops": round(tf, 1), "frac_bf16_peak": round(tf / BF16_PEAK_TFLOPS, 4),
-                    "mfma_issue_frac": round(mfma_equiv * tf / BF16_PEAK_TFLOPS, 4), "hbm_gbs": round(byts / us * 1e-3, 1)}
+    out["rows_%d" % n_matrix] = shape(net.X, n_matrix, n_matrix, False)
+    xd = distinct_rows(dev, d.Kp, 16384)
+    out["distinct_4096"] = shape(xd[:4096], 4096, 4096, True)
+    out["distinct_16384"] = shape(xd, 16384, 16384, True)
+    return out
 
-        def timed(prep, run, mfma_equiv, byts):
-            prep()
-            us_prep = _time_graphed(prep, 10)
-            us = _time_graphed(run, iters)
-            r = rec(us, mfma_equiv, byts)
-            r["us_prep"] = round(us_prep, 1)
-            us_b = _time_burst(run)
-            r["burst_of_3"] = {"us": round(us_b, 1), "frac_bf16_peak": round(flops / us_b * 1e-6 / BF16_PEAK_TFLOPS, 4)}
-            r["frac_bf16_peak_incl_prep"] = round(flops / (us + us_prep) * 1e-6 / BF16_PEAK_TFLOPS, 4)
-            return r
 
-        def product_path(Xm, pitch, packed, image, digits, us_with_reduce):
-            """The alternative built and measured in round 4 (loc_tuning.gemm_reduce = 1; NOT the default, it is slower): the GEMM
-            kernel without its reduction launch (loc_l1_forward_gemm_i8_partial) and the hidden-stack launch adding the group
-            partial sums up in its input stage.  us_gemm_kernel = the GEMM alone; us_stack / us_stack_fused = the hidden-stack
-            launch (what follows the GEMM in a predict) fed from a1 / from the partial sums; us_layer1 = us_gemm_kernel + what
-            the fusion adds to the stack launch, to be read against us_with_reduce_launch (the default)."""
-            groups, cv = C.c_int(0), C.c_void_p()
-            yh = torch.empty((n_rows, 2), device=dev)
-            runk = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_partial(Xm.data_ptr(), pitch, packed, rows.data_ptr(), n_rows,
-                                                                         C.byref(d), image.data_ptr(), digits, 2,
-                                                                         partial.data_ptr(), partial.numel(), 0, None,
-                                                                         C.byref(groups), C.byref(cv), st()))
-            runk()
-            mp = (n_rows + 127) // 128 * 128
-            args_tail = (P + 4 * lay.wh, P + 4 * lay.bh, P + 4 * lay.wa, P + 4 * lay.ba, P + 4 * lay.wb, P + 4 * lay.bb, d.Hp, d.L,
-                         n_rows, None, None, yh.data_ptr(), None, st)
-            run_s = lambda: _lib.check(lib.loc_stack_forward_eval(a1.data_ptr(), *args_tail[:-1], st()))
-            run_f = lambda: _lib.check(lib.loc_stack_forward_eval_partial(partial.data_ptr(), groups.value, mp * d.Hp, cv,
-                                                                         P + 4 * lay.b1, *args_tail[:-1], 0, st()))
-            us_k = _time_graphed(runk, iters)
-            it_s = max(3, iters // 4)
-            us_s, us_f = _time_graphed(run_s, it_s), _time_graphed(run_f, it_s)
-            us_l1 = us_k + max(0.0, us_f - us_s)
-            return {"us_gemm_kernel": round(us_k, 1), "groups": groups.value, "us_stack": round(us_s, 1),
-                    "us_stack_fused": round(us_f, 1), "us_layer1": round(us_l1, 1),
-                    "frac_bf16_peak": round(flops / us_l1 * 1e-6 / BF16_PEAK_TFLOPS, 4),
-                    "us_with_reduce_launch": us_with_reduce}
+MAX_LINE_BYTES = 4096        # the driver keeps a bounded tail of stdout: the headline line must fit it whole
 
-        for digits in (3, 2):
-            if lib.loc_l1_gemm_i8_supported(d.Hp, digits):
-                image = torch.empty(lib.loc_l1_image_i8_bytes(C.byref(d), digits), dtype=torch.uint8, device=dev)
-                prep = lambda: _lib.check(lib.loc_l1_image_i8_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, digits,
-                                                                    image.data_ptr(), st()))
-                run = lambda: _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n_rows,
-                                                                    C.byref(d), image.data_ptr(), digits, 2,
-                                                                    P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
-                                                                    a1.data_ptr(), 0, None, st()))
-                key = "int8x%d" % digits
-                out[key] = timed(prep, run, 0.5 * digits, n_rows * d.K + 1.0 * digits * d.K * d.H)
-                out[key]["tolerance"] = PREDICT_MODE_INFO[key]
-                out[key]["reduce_fused_into_stack"] = product_path(X, X.stride(0), 0, image, digits, out[key]["us"])
-                # the same GEMM reading a 2-bit packed copy of the matrix (--predict_packed / loc_net.X2; not the default:
-                # packing costs one pass over the matrix, see us_pack): bit-identical activations
-                X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
-                pack = lambda: _lib.check(lib.loc_pack_genotypes_2bit(X.data_ptr(), X.stride(0), X.shape[0], d.Kp,
-                                                                      X2.data_ptr(), X2.stride(0), st()))
-                pack()
-                runp = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr(), X2.stride(0), rows.data_ptr(),
-                                                                            n_rows, C.byref(d), image.data_ptr(), digits,
-                                                                            P + 4 * lay.b1, partial.data_ptr(),
-                                                                            partial.numel(), a1.data_ptr(), 0, None, st()))
-                keyp = key + "_packed2bit"
-                out[keyp] = timed(prep, runp, 0.5 * digits, n_rows * d.K / 4 + 1.0 * digits * d.K * d.H)
-                out[keyp]["reduce_fused_into_stack"] = product_path(X2, X2.stride(0), 1, image, digits, out[keyp]["us"])
-                out[keyp]["us_pack"] = round(_time_graphed(pack, 5), 1)
-                out[keyp]["tolerance"] = PREDICT_MODE_INFO[key] + "; --predict_packed: genotypes 0..3 stored 2 bits each (loc_pack_genotypes_2bit)"
-                del image, X2
-        for pieces in (3, 2, 1):
-            key = "bf16x%d" % pieces
-            if lib.loc_l1_gemm_supported(d.Hp, pieces):
-                image = torch.empty(lib.loc_l1_image_bytes(C.byref(d), pieces), dtype=torch.uint8, device=dev)
-                prep = lambda: _lib.check(lib.loc_l1_image_build(C.byref(d), bn4.data_ptr(), P + 4 * lay.w1, pieces,
-                                                                 image.data_ptr(), st()))
-                run = lambda: _lib.check(lib.loc_l1_forward_gemm(X.data_ptr(), X.stride(0), rows.data_ptr(),
-                                                                 n_rows, C.byref(d), image.data_ptr(), pieces,
-                                                                 P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
-                                                                 a1.data_ptr(), 0, st()))
-                out[key] = timed(prep, run, pieces, n_rows * d.K + 2.0 * pieces * d.K * d.H)
-                out[key]["tolerance"] = PREDICT_MODE_INFO[key]
-                del image
-            if in_loop and pieces != 2 and lib.loc_l1_rows_supported(d.Hp, pieces):
-                run = lambda: _lib.check(lib.loc_l1_forward_rows(X.data_ptr(), X.stride(0), rows.data_ptr(),
-                                                                 n_rows, C.byref(d), bn4.data_ptr(), P + 4 * lay.w1,
-                                                                 P + 4 * lay.b1, partial.data_ptr(), partial.numel(),
-                                                                 a1.data_ptr(), pieces, 0, None, st()))
-                out.setdefault("in_loop_conversion", {})[key] = rec(_time_graphed(run, iters), pieces,
-                                                                    n_rows * d.K + 4.0 * d.K * d.H)
-        return out
 
-    res = shape(net.X, n_matrix, n_matrix)
-    res["peak_tflops"] = BF16_PEAK_TFLOPS
-    g = net.quant_guard()
-    res["default_mode"] = {"flag": "--predict_mode auto (the CLI default)",
-                           "guard": {"median_range": round(g[0], 1), "max_range": round(g[1], 1)},
-                           "digit_planes": int(g[2]),
-                           "takes": ("int8x%d" % int(g[2]) if g[2] > 0 else "bf16x3") + ", from the 2-bit packed matrix for chunks of "
-                                    ">= 3072 rows (packed automatically when the genotypes are <= 3); the hidden stack that follows takes the "
-                                    "fp32 matrix pipe from 3072 rows per chunk (us_stack)"}
-    res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
-                     "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
-    res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)
-    res["jacknife_shape_16384_rows"] = shape(net.X, 16384, n_matrix, in_loop=False)     # one LOC_PREDICT_CHUNK
-    if x_distinct is not None:
-        res["distinct_4096_rows"] = shape(x_distinct[:4096], 4096, 4096, in_loop=False)
-        if x_distinct.shape[0] >= 16384:
-            res["distinct_16384_rows"] = shape(x_distinct, 16384, 16384, in_loop=False)
-    return res
+def format_line(out):
+    """The ONE JSON line of the run: strict JSON (no NaN / Infinity), at most MAX_LINE_BYTES.  Optional detail is dropped -
+    never the contract keys - should the line outgrow the bound; a line that still does not fit is an error, not output."""
+    def dumps(o):
+        return json.dumps(o, allow_nan=False, separators=(", ", ": "))
 
+    def scrub(o):
+        if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+            return None
+        if isinstance(o, dict):
+            return {k: scrub(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [scrub(v) for v in o]
+        return o
+
+    out = scrub(out)
+    line = dumps(out)
+    for path in (("cpu_baseline", "numpy_port"), ("roofline", "traffic_source"), ("config", "step"), ("l1_gemm",)):
+        if len(line) <= MAX_LINE_BYTES:
+            break
+        o = out
+        for k in path[:-1]:
+            o = o.get(k) or {}
+        o.pop(path[-1], None)
+        line = dumps(out)
+    if len(line) > MAX_LINE_BYTES:
+        raise RuntimeError(f"bench line is {len(line)} bytes (> {MAX_LINE_BYTES})")
+    missing = [k for k in REQUIRED_KEYS if k not in out]
+    if missing:
+        raise RuntimeError(f"bench line lacks {missing}")
+    return line
+
+
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 def cpu_baseline(x, y_norm, train, test, K, H, seconds):
     """torch-CPU fp32 restatement of the same epochs on the host's physical cores (oracle/torch_cpu.py), plus the NumPy
@@ -399,6 +290,8 @@ def main():
                          "some CUs with one backward workgroup so a second fit's stack waves can co-reside)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l1-gemm", action="store_true")
+    ap.add_argument("--l1-gemm-full", default=None, metavar="FILE",
+                    help="also run the full predict-mode x shape GEMM sweep (tools/l1_gemm_sweep.py) and write it to FILE")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each epoch")
     ap.add_argument("--side-stats", action="store_true",
@@ -600,21 +493,20 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_l1_gemm:
-            # 16,384 DISTINCT synthetic rows (0/1/2 genotypes drawn on the device, 4096 at a time) for the streaming shapes
-            # of the GEMM: the first 4096 of them, and all of them = one LOC_PREDICT_CHUNK launch of loc_predict
-            g = torch.Generator(device=dev).manual_seed(4096)
-            xd = torch.empty((16384, fits[0].net.d.Kp), dtype=torch.uint8, device=dev)
-            for r0 in range(0, 16384, 4096):
-                u = torch.rand((4096, fits[0].net.d.Kp), device=dev, generator=g)
-                xd[r0:r0 + 4096] = (u < 0.25).to(torch.uint8) + (u < 0.08).to(torch.uint8)
-                del u
-            out["l1_gemm"] = l1_gemm_roofline(fits[0].net, n, x_distinct=xd)
-            del xd
+            out["l1_gemm"] = l1_gemm_summary(fits[0].net, n)
+            if args.l1_gemm_full:
+                # the full predict-mode x shape sweep goes to a FILE, never into the line (round 4's 24 KB line was unparseable)
+                from tools import l1_gemm_sweep
+                full = l1_gemm_sweep.l1_gemm_roofline(fits[0].net, n, x_distinct=l1_gemm_sweep.distinct_rows(dev, fits[0].net.d.Kp))
+                full["tolerances"] = l1_gemm_sweep.PREDICT_MODE_INFO
+                with open(args.l1_gemm_full, "w") as f:
+                    json.dump(full, f, indent=1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, np.nan_to_num(ynorm), train, test, K, H, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        print(format_line(out), flush=True)          # the LAST thing this process prints
     if world > 1:
         dist.destroy_process_group()
 

@@ -92,6 +92,10 @@ def build_parser():
     p.add_argument("--unit_timeout", default=0, type=float,
                    help="seconds one --windows / --bootstrap replicate may take inside a worker before that worker is "
                         "killed and replaced and the replicate reported as failed (default 0: no limit)")
+    p.add_argument("--in_process", default=False, action="store_true",
+                   help="--windows / --bootstrap on ONE GPU: run the replicate fits on threads of this process instead of a "
+                        "worker process (saves the worker's start-up; no crash isolation, and --unit_timeout then still "
+                        "forces a worker process: only a process can be killed)")
     p.add_argument("--no_graph", default=False, action="store_true", help="do not capture epochs into HIP graphs")
     p.add_argument("--no_chain", default=False, action="store_true",
                    help="one layer-1 forward launch per minibatch step instead of chaining it into the previous step's "
@@ -741,7 +745,8 @@ def main(argv=None):
                                         host_prepare=_load_window_on_loader_thread if lazy_windows else None,
                                         unit_timeout=getattr(args, "unit_timeout", 0),
                                         max_workers=_unit_count_bound(),
-                                        procs_per_gpu=getattr(args, "procs_per_gpu", 1)).start()
+                                        procs_per_gpu=getattr(args, "procs_per_gpu", 1),
+                                        isolate=True if not getattr(args, "in_process", False) else None).start()
     try:
         return _main_body(pool, t_program)
     finally:

@@ -234,6 +234,9 @@ class ReplicatePool:
     host_prepare  optional per-unit hook `f(unit, args) -> unit` run on a LOADER THREAD of the worker: the parent keeps
                   two units in flight per worker, so the host work of unit i + 1 (zarr slice + filters, 2 s per
                   150k-variant window) overlaps the fit of unit i instead of sitting on its critical path
+    isolate       True: even a single worker is a separate process (crash isolation: a HIP abort in a fit costs that worker,
+                  its units are retried on a fresh one); None = only when unit_timeout > 0 (a hung fit can be killed only
+                  as a process); False = a single worker runs inside the calling process.
     unit_timeout  seconds a unit may spend in a worker after it reported ("start", i), or an otherwise idle worker may
                   spend on a unit's host work before that report; a worker that exceeds it is
                   killed (its exact process, never a pattern), the unit becomes an error record and a FRESH process
@@ -246,7 +249,7 @@ class ReplicatePool:
     two messages requeues the unit the same way."""
 
     def __init__(self, args, fit_fn, n_gpus=None, fits_per_gpu=1, prepare=None, host_prepare=None, log=print,
-                 poll_s=1.0, unit_timeout=0.0, max_workers=None, procs_per_gpu=None):
+                 poll_s=1.0, unit_timeout=0.0, max_workers=None, procs_per_gpu=None, isolate=None):
         """fits_per_gpu concurrent fits per GPU, run by procs_per_gpu worker processes per GPU (None = fits_per_gpu: one fit
         per process, the rounds 1-3 layout) with ceil(fits_per_gpu / procs_per_gpu) fit threads each, every thread on its
         own stream.  max_workers caps the CONCURRENT FITS (= the number of units, usually)."""
@@ -274,13 +277,17 @@ class ReplicatePool:
                          "fit_threads": self.threads}
         self.failed_starts = 0
         self._slot = 0
+        # --unit_timeout promises that a hung fit is killed and replaced: only a worker PROCESS can be killed, so a timeout
+        # keeps even a single worker out of this process (round 4's single-GPU default ran in-process and ignored the flag)
+        # isolate=True asks for the same without a timeout: a HIP abort in one fit then costs a worker, not the whole run.
+        self.isolate = (self.unit_timeout > 0) if isolate is None else bool(isolate)
 
     # ------------------------------------------------------------------ processes
     def start(self):
         """Spawn the workers now (no-op for a single in-process worker).  Returns self."""
-        if (self.n <= 1 and self.threads <= 1) or self.workers:
+        if self.workers:
             return self
-        if self.n <= 1:
+        if self.n <= 1 and not self.isolate:
             return self                     # one process = this one: run() drives the fit threads itself
         import torch.multiprocessing as mp
         self.ctx = mp.get_context("spawn")
@@ -307,7 +314,7 @@ class ReplicatePool:
         tl = self.timeline
         tl["run_started"] = time.time()
         out = [None] * len(units)
-        if self.n <= 1 or len(units) <= 1 and not self.workers:
+        if not self.workers and not self.isolate and (self.n <= 1 or len(units) <= 1):
             # one worker process = this process: `threads` fit threads, each on its own stream, fed by ONE loader thread
             # that prepares the host side of the next units (at most threads + 1 prepared-or-fitting at a time)
             import threading
@@ -399,7 +406,10 @@ class ReplicatePool:
             except (OSError, ValueError):        # the worker vanished between two messages: its units go back
                 bury(conn, "pipe closed")
 
-        def bury(conn, why):
+        def bury(conn, why, culprit=None):
+            """The worker behind `conn` is gone.  culprit = the unit known to have caused it (the one that timed out): an error
+            record at once.  Every other unit it held - fitting on a sibling thread, or only prefetched - goes back to the
+            queue and fails only when a SECOND worker is lost with it in hand (a crash does not say which fit thread aborted)."""
             w = workers.pop(conn, None)
             if w is None:
                 return
@@ -408,15 +418,15 @@ class ReplicatePool:
             except OSError:
                 pass
             w["p"].join(5)
-            victims = set(w["active"]) if w["active"] else set(w["inflight"][:1])
             for i in w["inflight"]:
                 if out[i] is not None:
                     continue
-                if i in victims or attempts.get(i, 0) >= 2:
+                if i == culprit or attempts.get(i, 0) >= 2:
+                    what = "while fitting this unit" if (i in w["active"] or i == culprit) else "twice with this unit in hand"
                     record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": w["gpu"],
-                            "error": f"worker process died ({why}, exit code {w['p'].exitcode}) while fitting this unit"})
+                            "error": f"worker process died ({why}, exit code {w['p'].exitcode}) {what}"})
                 else:
-                    retry.append(i)                      # only prefetched, never started: another worker takes it
+                    retry.append(i)                      # another worker (or the replacement) takes it
             if not w["inflight"] and why not in ("retired",):
                 self.failed_starts += 1
             if state["got"] < len(units) and (retry or state["next"] < len(units)) and self.failed_starts < 4 * self.n:
@@ -484,14 +494,14 @@ class ReplicatePool:
                         self.log(f"replicate {units[slow].get('name', '?')} on GPU {w['gpu']} exceeded "
                                  f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
                         w["p"].kill()               # this exact process
-                        bury(conn, f"timed out after {self.unit_timeout:g} s")
+                        bury(conn, f"timed out after {self.unit_timeout:g} s", culprit=slow)
                     elif (self.unit_timeout and not w["active"] and w["inflight"]
                           and now - w["t_wait"] > self.unit_timeout):
                         # nothing fitting, yet the next unit never reported "start": its host work (loader thread) hangs
                         self.log(f"replicate {units[w['inflight'][0]].get('name', '?')} on GPU {w['gpu']}: host work exceeded "
                                  f"--unit_timeout {self.unit_timeout:g} s: killing its worker (pid {w['p'].pid})")
                         w["p"].kill()
-                        bury(conn, f"host work timed out after {self.unit_timeout:g} s")
+                        bury(conn, f"host work timed out after {self.unit_timeout:g} s", culprit=w["inflight"][0])
         finally:
             for shm in handles:
                 shm.close()
@@ -552,7 +562,7 @@ class ReplicatePool:
 
 
 def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=print, fits_per_gpu=1, poll_s=1.0,
-              host_prepare=None, unit_timeout=0.0, procs_per_gpu=None):
+              host_prepare=None, unit_timeout=0.0, procs_per_gpu=None, isolate=None):
     """Run every unit once; returns the result records in unit order (ReplicatePool started, run and closed here).
 
     units         list of dicts (small per-unit data; window units carry their window, not their genotypes)
@@ -560,7 +570,7 @@ def run_units(units, args, fit_fn, n_gpus=None, shared=None, prepare=None, log=p
                   attached by every worker (the 0.5 GB bootstrap matrix is not pickled 16 times)"""
     pool = ReplicatePool(args, fit_fn, n_gpus=n_gpus, fits_per_gpu=fits_per_gpu, prepare=prepare,
                          host_prepare=host_prepare, log=log, poll_s=poll_s, unit_timeout=unit_timeout,
-                         max_workers=len(units), procs_per_gpu=procs_per_gpu)
+                         max_workers=len(units), procs_per_gpu=procs_per_gpu, isolate=isolate)
     try:
         return pool.run(units, shared)
     finally:

@@ -385,6 +385,56 @@ def test_bench_launches_its_own_ranks_without_torchrun(repo_root):
     assert r.returncode == 2
 
 
+def test_bench_line_is_short_strict_json_with_the_contract_keys(repo_root):
+    """Round 4's line grew to 24 KB and the driver's bounded stdout tail could not be parsed (BENCH_r04.parsed = null).  The
+    line is built by bench.format_line: at most 4 KB, strict JSON (NaN / Infinity never appear), every contract key
+    present; optional detail is dropped before the bound is broken, and a line that cannot fit raises."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo_root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def fail(c):
+        raise AssertionError("non-finite constant %r in the bench line" % c)
+
+    shape = {"us": 123.4, "frac": 0.4567, "incl_prep": 0.3456, "packed": {"us": 120.1, "frac": 0.47, "incl_prep": 0.36}}
+    out = {"metric": "training samples/sec on 1000x100k-SNP matrix", "value": 184354.1, "unit": "samples/s", "n_gpus": 1,
+           "steps": 20, "warmup": 5, "ms_per_step": 4.3937, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "w" * 160, "step": "s" * 120, "width": 256, "nlayers": 10, "graph": True, "chained_steps": True,
+                      "epochs_in_flight": 2, "replicates_per_gpu": 1, "replicates": "single model"},
+           "us_per_minibatch_step": 168.99, "whole_step_hbm_frac": 0.5518, "final_loss": float("nan"), "final_val_loss": float("inf"),
+           "roofline": {"bound": "hbm", "kernel": "l1_bwd_adam_chain_kernel", "achieved": 5863.3, "peak": 8000.0, "unit": "GB/s",
+                        "frac": 0.7329, "traffic": 678083488, "traffic_source": "t" * 90, "bytes_per_launch": 653914409,
+                        "us_per_launch": 111.53, "launches_timed": 52},
+           "l1_gemm": {"mode": "int8x2", "peak_tflops": 2500.0, "guard_median": 28.1, "guard_max": 77.0, "us_prep": 60.4,
+                       "rows_1000": shape, "distinct_4096": shape, "distinct_16384": shape},
+           "cpu_baseline": {"value": 359.7, "unit": "samples/s", "cores": 16, "kind": "port", "impl": "i" * 90, "sample": "x" * 340,
+                            "last_loss": 0.5, "last_val_loss": 0.35, "numpy_port": {"value": 160.1, "unit": "samples/s", "sample": "y" * 120}}}
+    line = bench.format_line(out)
+    assert "\n" not in line and len(line.encode()) < 4096
+    got = json.loads(line, parse_constant=fail)
+    for k in bench.REQUIRED_KEYS:
+        assert k in got, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in got["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert got["final_loss"] is None and got["final_val_loss"] is None          # non-finite numbers become null, never NaN
+    assert "l1_gemm" in got                                                     # a normal line keeps its summary
+    # bloat is shed from the optional detail first ...
+    fat = dict(out, l1_gemm=dict(out["l1_gemm"], sweep=["r" * 300] * 40))
+    line = bench.format_line(fat)
+    got = json.loads(line, parse_constant=fail)
+    assert len(line) <= bench.MAX_LINE_BYTES and "l1_gemm" not in got and "roofline" in got and "cpu_baseline" in got
+    # ... and a line whose CONTRACT part cannot fit is an error rather than an unparseable record
+    with pytest.raises(RuntimeError):
+        bench.format_line(dict(out, config={"workload": "w" * 5000}))
+    with pytest.raises(RuntimeError):
+        bench.format_line({k: v for k, v in out.items() if k != "roofline"})
+
+
 def test_jacknife_draws_reproduce_the_reference_loop_and_its_rng_stream():
     """locator.py:713-727 draws, per replicate, the redrawn sites and then one np.random.binomial(2, af[i], n_pred)
     PER SITE in a Python loop.  jacknife_draws issues one broadcast binomial per replicate: same values, and the
@@ -639,6 +689,54 @@ def test_pool_kills_a_worker_whose_host_phase_hangs():
     for i in (0, 1, 3, 4):
         assert "error" not in res[i] and res[i]["value"] == 2 * i, res[i]
     assert any("host work exceeded --unit_timeout" in str(l) for l in logs)
+
+
+def _die_once_fit(unit, device="cpu"):
+    """A fit that takes its whole worker process down the FIRST time unit `die_once` runs (marker file), while a sibling
+    fit thread of that process is in the middle of another unit."""
+    import time
+    if unit.get("die_once") and not os.path.exists(unit["die_once"]):
+        time.sleep(0.3)                      # the sibling thread has started its own unit by now
+        open(unit["die_once"], "w").close()
+        os.kill(os.getpid(), 9)
+    time.sleep(0.6)
+    return {"name": unit["name"], "value": unit["replicate"] * 3, "seconds": 0.6, "pid": os.getpid()}
+
+
+def test_pool_requeues_the_sibling_fit_of_a_crashed_worker_and_isolates_a_single_worker_under_unit_timeout(tmp_path):
+    """ADVICE r04 (medium).  (1) One process x two fit threads (the default layout): a crash says nothing about WHICH fit
+    aborted, so every unit the worker held is tried once more and fails only when a second worker is lost with it - the
+    innocent sibling no longer becomes an error record (here even the culprit recovers: it dies only once).  (2) With
+    --unit_timeout a single worker is still a separate PROCESS (the in-process path cannot kill a hung fit): the hung unit
+    becomes an error record, its siblings are fitted by the replacement."""
+    import time
+    units = [dict(name=f"c{i}", replicate=i) for i in range(5)]
+    units[1]["die_once"] = str(tmp_path / "died")
+    logs = []
+    res = R.run_units(units, _Args(), _die_once_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=1, log=logs.append, poll_s=0.1,
+                      isolate=True)
+    assert [r["unit_index"] for r in res] == list(range(5))
+    assert all("error" not in r and r["value"] == 3 * i for i, r in enumerate(res)), res
+    assert len({r["pid"] for r in res}) >= 1 and os.getpid() not in {r["pid"] for r in res}
+    # (2)
+    pool = R.ReplicatePool(_Args(), _slow_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=1, host_prepare=_slow_host_prepare,
+                           log=logs.append, poll_s=0.1, unit_timeout=1.5)
+    assert pool.n == 1 and pool.threads == 2 and pool.isolate
+    units = [dict(name=f"t{i}", replicate=i) for i in range(5)]
+    units[2]["hang"] = True
+    t0 = time.time()
+    res = pool.run(units)
+    pool.close()
+    assert time.time() - t0 < 60
+    assert "timed out" in res[2]["error"]
+    for i in (0, 1, 3, 4):
+        assert "error" not in res[i] and res[i]["value"] == 2 * i and res[i]["pid"] != os.getpid(), res[i]
+    # without a timeout the single worker stays in this process (no spawn, no pickling of the units)
+    pool = R.ReplicatePool(_Args(), _slow_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=1, host_prepare=_slow_host_prepare,
+                           log=logs.append, poll_s=0.1)
+    res = pool.run([dict(name=f"p{i}", replicate=i) for i in range(3)])
+    pool.close()
+    assert all(r["pid"] == os.getpid() for r in res)
 
 
 def test_pool_reports_a_loader_thread_failure_instead_of_hanging(monkeypatch):
