@@ -586,7 +586,11 @@ def _load_window_on_loader_thread(unit, a):
     u = dict(unit)
     u["args"] = a
     if torch.cuda.is_available() and not getattr(a, "host_filter", False):
-        return _read_window(u)
+        gt = G.open_group(u["zarr"], mode="r")["calldata/GT"]
+        # the device filter takes the store's calls as they are: int8 [variants][samples][ploidy].  Any other dtype or
+        # rank goes the host way (np.asarray(..., dtype=int8) as load_genotypes does) instead of failing every window
+        if np.dtype(gt.dtype) == np.int8 and len(gt.shape) == 3:
+            return _read_window(u)
     return _load_window(u)
 
 

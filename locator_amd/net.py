@@ -356,10 +356,14 @@ class LocatorNet:
                                                 P + 4 * lay.mov_mean, P + 4 * lay.mov_var, _ptr(stats_ep), None, _stream()),
                    "loc_bn_epoch_finish")
 
-    def predict_rows(self, rows, n, yhat, dist=None):
-        """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y."""
+    def predict_rows(self, rows, n, yhat, dist=None, in_fit=False):
+        """Inference-mode forward for X[rows[:n]] into yhat [n,2]; dist [n] = distance to Y.
+        in_fit: the call is an epoch's validation sweep (train.EpochRunner.enqueue): its arithmetic must not depend on
+        whether the epoch is being captured, replayed or enqueued eagerly - val_loss drives the strict-'<' checkpoint /
+        early-stopping / LR decisions - so the dynamic-range guard (a host read-back per set of weights), the automatic
+        packing and the kept image are all out: many validation rows (>= 512) take three digit planes unconditionally."""
         lib, d = self.lib, self.d
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_current_stream_capturing() or bool(in_fit)
         digits = self.predict_digits if self.predict_digits != 0 else 3
         use_i8 = (self.predict_pieces > 0 and digits > 0 and n >= LOC_GEMM_I8_MIN_ROWS
                   and lib.loc_l1_gemm_i8_supported(d.Hp, digits))
@@ -400,16 +404,18 @@ class LocatorNet:
             net.predict_digits, net.predict_pieces, net.l1_scan_ready = keep
         # predict_locs predicts twice with the same weights (locator.py:414, :441): the second call finds the image
         mode = lib.loc_predict_image_mode(C.byref(net), int(n))
-        net.l1_image_ready = mode if (mode and mode == self._image_mode
-                                      and not torch.cuda.is_current_stream_capturing()) else 0
-        _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
-                                        _ptr(dist), _stream()), "loc_predict")
-        if mode:
-            self._image_mode = mode
-        # per-call choices never outlive the call
-        net.predict_digits = self.predict_digits if self.predict_digits != 0 else 3
-        net.predict_pieces = self.predict_pieces
-        net.l1_scan_ready = 0
+        net.l1_image_ready = mode if (mode and mode == self._image_mode and not capturing) else 0
+        try:
+            _lib.check(self.lib.loc_predict(C.byref(net), _ptr(rows), int(n), _ptr(yhat), 1 if dist is not None else 0,
+                                            _ptr(dist), _stream()), "loc_predict")
+            if mode:
+                self._image_mode = mode
+        finally:
+            # per-call choices never outlive the call, whether it succeeded or raised (the struct is cached)
+            net.predict_digits = self.predict_digits if self.predict_digits != 0 else 3
+            net.predict_pieces = self.predict_pieces
+            net.l1_scan_ready = 0
+            net.l1_image_ready = 0
 
     def quant_guard(self):
         """(median R, largest R, digit planes allowed, digit planes allowed in exact mode) of the current parameters, R_h =

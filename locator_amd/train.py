@@ -118,6 +118,7 @@ class EpochRunner:
             self.perm_dev2 = [self.perm_dev, torch.zeros_like(self.perm_dev)]
             self.stats_ep2 = [self.stats_ep, torch.zeros_like(self.stats_ep)]
             self.graphs = [None, None]
+            self._perm_promised = None       # what the last start_epoch uploaded for the epoch after it
             self.side_stats = bool(side_stats)
             self._side = None
             if len(self.perm_ring) < 3:       # two uploads at the first epoch, one per epoch after: never reuse a pending buffer
@@ -209,7 +210,7 @@ class EpochRunner:
             net.train_step(perm_dev[j * self.batch:], nb, j + 1, mask, self.stats[j:], e0, e1,
                            bn_ready=True, bn_next=nxt)
         if self.n_val:
-            net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:])
+            net.predict_rows(self.val_rows, self.n_val, self.val_yhat, self.stats[self.steps:], in_fit=True)
         if self.cb is not None:
             from . import _lib
             from .net import _ptr, _stream
@@ -243,7 +244,14 @@ class EpochRunner:
             p = e & 1
             if e == 0:
                 self._upload_perm(perm, self.perm_dev2[0], 0)
+            elif self._perm_promised is None or not np.array_equal(np.asarray(perm), self._perm_promised):
+                # epoch e trains on what the PREVIOUS call uploaded as perm_next (its first forward was computed from it):
+                # a caller that did not announce this permutation then (run_epoch, start_epoch without perm_next) would
+                # silently train on another one
+                raise ValueError("cross-epoch chaining: start_epoch(perm) must receive the permutation the previous call "
+                                 "passed as perm_next (use FitLoop, or EpochRunner(xchain=False) for one epoch at a time)")
             self._upload_perm(perm if perm_next is None else perm_next, self.perm_dev2[1 - p], e + 1)
+            self._perm_promised = np.array(perm if perm_next is None else perm_next)
         else:
             self._upload_perm(perm, self.perm_dev, e)
         if self.masks is not None:

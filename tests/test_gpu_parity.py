@@ -380,3 +380,44 @@ def test_pipelined_fit_matches_oracle_fit_with_callbacks():
     ref = O.predict(best, x[pr_rows])                 # fit reloads the best-val_loss weights (locator.py:379-388)
     rel = np.abs(yhat.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1.0)
     assert rel.max() < 1e-3, rel.max()
+
+
+def test_validation_sweep_arithmetic_does_not_depend_on_capture_with_many_validation_rows():
+    """with >= 512 validation rows the sweep takes the int8 matrix pipe.  In round 4 an EAGER epoch asked
+    the dynamic-range guard (host read-back, maybe two digit planes under --predict_mode auto) while a CAPTURED epoch ran
+    three planes unguarded, so val_loss - and every strict-'<' callback decision - depended on --no_graph / the replicate
+    layout.  predict_rows(in_fit=True) now pins the sweep: graph and eager fits agree bit for bit, and no guard is asked
+    (the fit never synchronises for it)."""
+    from locator_amd.train import fit
+    x, y, p, rng = make_problem(900, 1500, 64, 4, seed=9)
+    tr, va = np.arange(0, 300), np.arange(300, 900)                  # 600 validation rows
+    out = []
+    for use_graph in (True, False):
+        net = build_net(x, y, p, seed=3, predict_digits=0)          # the command line's default: auto
+        asked = []
+        real = net.quant_guard
+        net.quant_guard = lambda: asked.append(1) or real()
+        h = fit(net, tr, va, max_epochs=6, patience=6, use_graph=use_graph)
+        assert not asked, "the validation sweep consulted the guard"
+        out.append((h.history, net.params.cpu().numpy().copy()))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_cross_epoch_chaining_refuses_a_permutation_it_was_not_promised():
+    """with xchain an epoch trains on the permutation the PREVIOUS start_epoch uploaded as perm_next.
+    A direct EpochRunner user who skips perm_next (run_epoch) used to train every later epoch on the previous permutation
+    silently; now it is an error, and the FitLoop-style call sequence still works."""
+    from locator_amd.train import EpochRunner
+    x, y, p, rng = make_problem(100, 320, 64, 4, seed=5)
+    net = build_net(x, y, p, seed=2)
+    r = EpochRunner(net, np.arange(80), np.arange(80, 100), use_graph=False, xchain=True)
+    if not r.xchain:
+        pytest.skip("chained steps unsupported for this shape")
+    p0, p1, p2 = (np.random.default_rng(i).permutation(80) for i in range(3))
+    r.start_epoch(p0, perm_next=p1)
+    r.finish_epoch()
+    with pytest.raises(ValueError, match="perm_next"):
+        r.start_epoch(p2)                       # p1 was promised
+    r.start_epoch(p1, perm_next=p2)
+    r.finish_epoch()

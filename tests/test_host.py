@@ -365,6 +365,41 @@ def test_windows_fast_prologue_keeps_the_rng_stream(tmp_path, fixture_vcf):
             assert np.array_equal(a[k], b[k]), k
 
 
+def test_window_loader_falls_back_to_the_host_path_for_a_store_that_is_not_int8(tmp_path, fixture_vcf, monkeypatch):
+    """the GPU worker's loader thread decodes gt[a:b] straight into an int8 pinned view, which only an
+    int8 [variants][samples][ploidy] store allows.  A store with another dtype (allel writes int8, other tools may not)
+    used to fail EVERY window; now it takes the host slice + filter path, with the same rows as an int8 copy of it."""
+    import torch
+    gt, pos, samples = fixture_vcf["calldata/GT"][:1500], fixture_vcf["variants/POS"][:1500], fixture_vcf["samples"]
+    got = {}
+    for name, dt in (("i8", np.int8), ("i16", np.int16)):
+        store = str(tmp_path / f"{name}.zarr")
+        G.write_callset_zarr(store, gt, pos, samples, chunk_variants=512)
+        if dt is not np.int8:                   # rewrite calldata/GT in the other dtype
+            import shutil
+            shutil.rmtree(os.path.join(store, "calldata", "GT"))
+            G.write_zarr_array(os.path.join(store, "calldata", "GT"), np.asarray(gt).astype(dt), (512,) + tuple(np.shape(gt)[1:]))
+        L._setup(["--zarr", store, "--sample_data", SAMPLES, "--out", str(tmp_path / name), "--seed", "5", "--windows",
+                  "--window_size", str(int(pos[-1] + 1))])
+        smp, _ = L._prologue(force_full=False)
+        units = L._window_units(smp, lazy=True)
+        assert len(units) == 1
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+        if dt is np.int8:
+            seen = []
+            monkeypatch.setattr(L, "_read_window", lambda u: seen.append(u) or u)
+            L._load_window_on_loader_thread(units[0], L.args)
+            assert len(seen) == 1                                   # an int8 store goes the device way
+            monkeypatch.undo()
+            got[name] = L._load_window(dict(units[0], args=L.args))
+        else:
+            monkeypatch.setattr(L, "_read_window", lambda u: (_ for _ in ()).throw(AssertionError("int8-only path taken")))
+            got[name] = L._load_window_on_loader_thread(units[0], L.args)
+            monkeypatch.undo()
+    for k in ("traingen", "testgen", "predgen"):
+        assert got["i16"][k].dtype == got["i8"][k].dtype and np.array_equal(got["i8"][k], got["i16"][k]), k
+
+
 def test_bench_launches_its_own_ranks_without_torchrun(repo_root):
     """`python bench.py --gpus N` with no launcher: the parent starts N rank processes before touching a GPU, the
     ranks rendezvous on 127.0.0.1, barrier, take the max over ranks, and rank 0's single JSON line comes back through
