@@ -17,11 +17,12 @@
 // Genotypes above 127 and K ranges long enough to overflow an i32 (x_max * 128 * SNPs per group >= 2^31) are refused
 // here; loc_predict then takes the bf16 kernels of l1_gemm.hip / l1_rows.hip, which are exact for any uint8.
 //
-//   l1_colmax_kernel     per-unit max_k |s_k W1[k][h]| (order-independent: max over non-negative floats as uints)
+//   l1_scan_kernel       per-unit max_k |s_k W1[k][h]| (order-independent: max over non-negative floats as uints), and the
+//                        per-workgroup shares of sum_k |s_k W1[k][h]| (guard) and of the shift term sum_k t_k W1[k][h]
 //   l1_image_i8_kernel   W1S (fp32, swizzled) x BN scale -> HBM image of digit planes, one 16 KB tile per (64-SNP block,
 //                        digit plane), laid out [16-SNP chunk c][unit n][16 SNPs]: a wave's MFMA B operand for one
-//                        32-SNP step is two contiguous 512-byte runs.  Plane 0 is the most significant digit.  Also
-//                        the shift term's per-block partial sums (shared with l1_gemm.hip's cvec reduction).
+//                        32-SNP step is two contiguous 512-byte runs.  Plane 0 is the most significant digit.  One extra
+//                        workgroup (g8_tail) turns the scan's shares into the guard and the shift vector meanwhile.
 //   l1_gemm_i8_kernel    workgroup = 8 waves on a 128-row x 256-unit tile; the SNP range is split over groups, group g
 //                        owning a CONTIGUOUS run of pairs of 64-SNP blocks.  A wave owns 32 units and ALL 128 rows: its
 //                        digit fragments go HBM/L2 -> VGPRs (12 fragments = 1.5 pairs in flight, saddr-form requests),
@@ -56,42 +57,71 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------
 // per-unit scale and digit image
 // ---------------------------------------------------------------------------------------------------------
-// Thread = unit n (the addressing of l1_image_kernel), workgroup b walks the 64-SNP blocks b, b + grid, ...: one atomicMax
-// per unit and workgroup at the end (a few hundred workgroups, not one per block: the atomics all hit the same 256
-// words).  colmax[n] = max |s_k W1[k][n]| as the bit pattern of a non-negative float: the maximum is order-independent,
-// so the result is deterministic.
-// The same pass also leaves sumabs_part[workgroup][n] = this workgroup's share of sum_k |w'| (fixed order inside a
-// workgroup; l1_quant_guard_kernel adds the shares in workgroup order): the unit's TYPICAL weight, against which its
-// largest weight decides how many digit planes the weights need (dynamic range guard below).  The mean magnitude, not
-// the rms: one weight 3000 x the rest moves the rms of 100,000 weights by 10 x (max / rms can never exceed sqrt(K), and
-// the first version of this guard, built on the rms, let exactly that case through) but the mean by 3 %.
-__global__ __launch_bounds__(G8_HP) void l1_colmax_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
-                                                          int Kp, int nkt64, uint32_t* __restrict__ colmax,
-                                                          float* __restrict__ sumabs_part) {
+// Workgroup b walks the 64-SNP blocks b, b + grid, ...; one atomicMax per unit and workgroup at the end (a few hundred
+// workgroups, not one per block: the atomics all hit the same 256 words).  colmax[n] = max |s_k W1[k][n]| as the bit pattern
+// of a non-negative float: the maximum is order-independent, so the result is deterministic.
+// The same pass also leaves two shares per workgroup, added up in workgroup order by g8_tail (the image kernel's extra
+// workgroup) or by l1_quant_guard_kernel:
+//   sumabs_part[workgroup][n]  its share of sum_k |w'|: the unit's TYPICAL weight, against which its largest weight decides
+//                              how many digit planes the weights need (dynamic range guard below).  The mean magnitude, not
+//                              the rms: one weight 3000 x the rest moves the rms of 100,000 weights by 10 x (max / rms can
+//                              never exceed sqrt(K), and the first version of this guard, built on the rms, let exactly that
+//                              case through) but the mean by 3 %.
+//   csum_part[workgroup][n]    its share of the shift term sum_k t_k W1[k][n] (round 5: it used to be a by-product of the
+//                              image kernel plus a launch of l1_image_cvec_kernel; here it costs one FMA per weight)
+// Addressing (round 5): a lane reads 16 bytes = the four units 4 c .. 4 c + 3 of ONE SNP (W1S keeps them adjacent), the
+// four lanes of a quad take SNPs kl = 4 j + c4 - 8 requests per thread and 32-SNP tile instead of 32 four-byte ones - and
+// the per-unit statistics of the quad's four lanes meet once, at the end, in a fixed order.
+__global__ __launch_bounds__(G8_HP) void l1_scan_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
+                                                        int Kp, int nkt64, uint32_t* __restrict__ colmax,
+                                                        float* __restrict__ sumabs_part, float* __restrict__ csum_part) {
     constexpr int nht = G8_HP / 32;
     const int n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
-    float mx = 0.f, ss = 0.f;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
     for (int kt64 = blockIdx.x; kt64 < nkt64; kt64 += gridDim.x) {
 #pragma unroll
         for (int h32 = 0; h32 < 2; ++h32) {
             const int kt32 = 2 * kt64 + h32;
             if (kt32 * 32 < Kp) {
-                const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128 + c4;
-                float m4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128;
+                f32x4 v[8];
+                float sc[8], sh[8];
 #pragma unroll
-                for (int kl = 0; kl < 32; ++kl) {
-                    const float w = src[kl * 4] * ss4[kt32 * 32 + kl];
-                    m4[kl & 3] = fmaxf(m4[kl & 3], fabsf(w));
-                    s4[kl & 3] += fabsf(w);
+                for (int j = 0; j < 8; ++j) {
+                    const int kl = 4 * j + c4;
+                    v[j] = *reinterpret_cast<const f32x4*>(src + kl * 4);
+                    sc[j] = ss4[kt32 * 32 + kl];
+                    sh[j] = ss4[Kp + kt32 * 32 + kl];
                 }
-                mx = fmaxf(mx, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
-                ss += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = fabsf(v[j][u] * sc[j]);
+                        mx[u] = fmaxf(mx[u], a);
+                        ss[u] += a;
+                        cs[u] = fmaf(sh[j], v[j][u], cs[u]);
+                    }
             }
         }
     }
-    if (mx > 0.f) atomicMax(colmax + n, fbits(mx));
-    sumabs_part[(int64_t)blockIdx.x * G8_HP + n] = ss;
+    // the quad's four lanes hold the same four units over different SNPs: (lane 0 + lane 1) + (lane 2 + lane 3), then lane c4
+    // keeps unit c4 = its own
+    float mxo = 0.f, sso = 0.f, cso = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float m = fmaxf(mx[u], __shfl_xor(mx[u], 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        float a = ss[u] + __shfl_xor(ss[u], 1);
+        a = a + __shfl_xor(a, 2);
+        float c = cs[u] + __shfl_xor(cs[u], 1);
+        c = c + __shfl_xor(c, 2);
+        if (u == c4) { mxo = m; sso = a; cso = c; }
+    }
+    if (mxo > 0.f) atomicMax(colmax + n, fbits(mxo));
+    sumabs_part[(int64_t)blockIdx.x * G8_HP + n] = sso;
+    csum_part[(int64_t)blockIdx.x * G8_HP + n] = cso;
 }
 
 // Dynamic-range guard of the fixed-point image.  A unit's weights share one power-of-two step delta_h chosen from its
@@ -192,22 +222,91 @@ __device__ __forceinline__ float digit_delta(float mx) {
     return ldexpf(1.f, e);
 }
 
+// The once-per-image leftovers, done by ONE extra workgroup of the image kernel while the others convert tiles (round 5: they
+// used to be two launches, l1_quant_guard_kernel and l1_image_cvec_kernel, 9 + 5 us on the stream): the workgroup shares of
+// the scan are added in workgroup order -> guard[0..3] (as l1_quant_guard_kernel) and cvec8[0][n] = the shift term
+// sum_k t_k W1[k][n], cvec8[1..7][n] = 0 (l1_gemm_reduce_kernel adds eight slices).  256 threads, thread = unit.
+__device__ __forceinline__ void g8_tail(const uint32_t* __restrict__ colmax, const float* __restrict__ sumabs_part,
+                                        const float* __restrict__ csum_part, int nparts, int K, int H,
+                                        float* __restrict__ guard, float* __restrict__ cvec8) {
+    __shared__ __attribute__((aligned(16))) float R[G8_HP];
+    __shared__ float red[4];
+    __shared__ float s_med;
+    const int n = threadIdx.x;
+    float sa[8], ca[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sa[e] = ca[e] = 0.f;
+    int b = 0;
+    for (; b + 8 <= nparts; b += 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sa[e] += sumabs_part[(int64_t)(b + e) * G8_HP + n];
+            ca[e] += csum_part[(int64_t)(b + e) * G8_HP + n];
+        }
+    }
+    for (int e = 0; b < nparts; ++b, ++e) {
+        sa[e] += sumabs_part[(int64_t)b * G8_HP + n];
+        ca[e] += csum_part[(int64_t)b * G8_HP + n];
+    }
+    const float ss = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+    const float cs = ((ca[0] + ca[1]) + (ca[2] + ca[3])) + ((ca[4] + ca[5]) + (ca[6] + ca[7]));
+    cvec8[n] = cs;
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) cvec8[sl * G8_HP + n] = 0.f;
+    const float mx = bitsf(colmax[n]);
+    const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
+    const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
+    R[n] = r;
+    __syncthreads();
+    // median by rank counting: the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
+    int rank = 0;
+    const f32x4* R4 = reinterpret_cast<const f32x4*>(R);
+#pragma unroll 4
+    for (int j4 = 0; j4 < G8_HP / 4; ++j4) {
+        const f32x4 v = R4[j4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * j4 + e;
+            rank += (j < H && (v[e] < r || (v[e] == r && j < n))) ? 1 : 0;
+        }
+    }
+    float wmax = r;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if ((n & 63) == 0) red[n >> 6] = wmax;
+    if (n < H && rank == (H - 1) / 2) s_med = r;
+    __syncthreads();
+    if (n == 0) {
+        const float rmed = s_med, rmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        guard[0] = rmed;
+        guard[1] = rmax;
+        const float exact = rmax <= LOC_GUARD_EXACT_MAX ? 3.f : -1.f;
+        guard[2] = (rmed <= LOC_GUARD_FAST_MEDIAN && rmax <= LOC_GUARD_FAST_MAX) ? 2.f : exact;
+        guard[3] = exact;
+    }
+}
+
 // tiles[(kt64*DT + p)][c][n][e] = digit plane p (0 = most significant) of q = rint(s_k W1[k][n] / delta_n),
-// k = kt64*64 + c*16 + e;  cpart[kt64][n] = sum over the block's SNPs of t_k W1[k][n];  delta[n] written by block 0.
+// k = kt64*64 + c*16 + e;  delta[n] written by the first tile workgroup.  Workgroup 0 is g8_tail; workgroup 1 + kt64 converts
+// 64-SNP block kt64.
 template <int DT>
 __global__ __launch_bounds__(G8_HP) void l1_image_i8_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
-                                                            int Kp, const uint32_t* __restrict__ colmax,
+                                                            int Kp, int K, int H, const uint32_t* __restrict__ colmax,
                                                             float* __restrict__ delta, unsigned char* __restrict__ tiles,
-                                                            float* __restrict__ cpart) {
+                                                            const float* __restrict__ sumabs_part,
+                                                            const float* __restrict__ csum_part, int nparts,
+                                                            float* __restrict__ guard, float* __restrict__ cvec8) {
+    if (blockIdx.x == 0) {
+        g8_tail(colmax, sumabs_part, csum_part, nparts, K, H, guard, cvec8);
+        return;
+    }
     constexpr int nht = G8_HP / 32;
-    const int kt64 = blockIdx.x, n = threadIdx.x;
+    const int kt64 = blockIdx.x - 1, n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
     const float* scale = ss4;
-    const float* shift = ss4 + Kp;
     const float dl = digit_delta<DT>(bitsf(colmax[n]));
     const float inv = 1.0f / dl;                          // a power of two: exact
     if (kt64 == 0) delta[n] = dl;
-    float csum = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int kt32 = 2 * kt64 + (c >> 1);
@@ -220,7 +319,6 @@ __global__ __launch_bounds__(G8_HP) void l1_image_i8_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) {
                 const int kl = (c & 1) * 16 + e, k = kt32 * 32 + kl;
                 const float w = src[kl * 4];
-                csum = fmaf(shift[k], w, csum);
                 int qv = (int)rintf((w * scale[k]) * inv);
                 // signed base-256 digits, least significant first; the top digit takes what is left
                 int dg[DT];
@@ -242,7 +340,6 @@ __global__ __launch_bounds__(G8_HP) void l1_image_i8_kernel(const float* __restr
             *reinterpret_cast<u32x4*>(tiles + ((int64_t)kt64 * DT + p) * G8_TILE + c * (G8_HP * 16) + n * 16) = v;
         }
     }
-    cpart[(int64_t)kt64 * G8_HP + n] = csum;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -297,7 +394,8 @@ constexpr int g8_heads(int j, int FP, int NB) { return NB > j ? (NB - j + FP - 1
 
 // Timing ablations (never in the product build: `make ablate A=<bits>` writes ../liblocator_hip_ablate<bits>.so, results
 // are wrong by construction): 1 no fragment requests in the loop, 2 no genotype DMAs, 4 no rendezvous, 8 no A-fragment
-// reads, 16 genotype DMA always from the group's first pair (L2-hot).
+// reads, 16 genotype DMA always from the group's first pair (L2-hot), 64 no global stores of the partial sums (the LDS staging
+// stays), 128 no epilogue at all.
 #ifndef LOC_GEMM_ABLATE
 #define LOC_GEMM_ABLATE 0
 #endif
@@ -591,6 +689,19 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
     float* const ep = reinterpret_cast<float*>(g8_smem) + c.w * (G8_BM * WU);
     float* const pout = partial + ((int64_t)g * Mp + mt * G8_BM) * G8_HP + c.w * WU;
     auto emit = [&](const i32x16 (&hi_p)[UT][4], const i32x16 (&lo_p)[UT][4], float s_hi, float s_lo, bool add) {
+#if LOC_GEMM_ABLATE & 128
+        {   // keep the accumulators alive without the epilogue: one word per lane that is (almost) never stored
+            int keep = 0;
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep ^= hi_p[ut][tm][r] ^ lo_p[ut][tm][r];
+            if (keep == 0x7fffffff && s_hi == -1.f) pout[0] = (float)keep;
+            return;
+        }
+#endif
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
@@ -607,6 +718,9 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
             f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * WU + c4);
             f32x4* dst = reinterpret_cast<f32x4*>(pout + (int64_t)row * G8_HP + c4);
             if (add) v = v + *dst;
+#if LOC_GEMM_ABLATE & 64
+            if (v[0] != 12345.678f) continue;           // (timing build: the store almost never happens)
+#endif
             *dst = v;
         }
     };
@@ -632,37 +746,43 @@ static int g8_nkt64(const loc_dims* d) { return ((d->Kp + G8_BK - 1) / G8_BK + 1
 
 extern "C" int loc_l1_gemm_i8_supported(int Hp, int digits) { return Hp == G8_HP && (digits == 2 || digits == 3); }
 
-// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][guard: Hp floats, 4 used][cpart: nkt64*Hp floats][tiles],
-// 1 KB aligned sections.  The scan (colmax + guard) borrows the cpart section for its per-workgroup sums of squares; the
-// image kernel overwrites it afterwards.
+// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][guard: Hp floats, 4 used][shares: 2*grid*Hp floats][tiles],
+// 1 KB aligned sections; shares = the scan's per-workgroup sums (sum |w'| first, then the shift term), grid = g8_scan_grid.
 static int64_t g8_delta_off() { return 8 * G8_HP * 4; }
 static int64_t g8_colmax_off() { return g8_delta_off() + G8_HP * 4; }
 static int64_t g8_guard_off() { return g8_colmax_off() + G8_HP * 4; }
 static int64_t g8_cpart_off() { return g8_guard_off() + G8_HP * 4; }
+static int g8_scan_grid(const loc_dims* d) { const int nkt = g8_nkt64(d); return nkt < 256 ? nkt : 256; }   // one workgroup per compute unit
 static int64_t g8_tiles_off(const loc_dims* d) {
-    return (g8_cpart_off() + (int64_t)g8_nkt64(d) * G8_HP * 4 + 1023) / 1024 * 1024;
+    return (g8_cpart_off() + (int64_t)2 * g8_scan_grid(d) * G8_HP * 4 + 1023) / 1024 * 1024;
 }
 extern "C" int64_t loc_l1_image_i8_bytes(const loc_dims* d, int digits) {
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) return 0;
     return g8_tiles_off(d) + (int64_t)g8_nkt64(d) * digits * G8_TILE;
 }
 
-// colmax + per-unit rms -> guard (see l1_quant_guard_kernel); the image kernels read colmax from the same header
-extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, void* stream) {
+// colmax + per-unit mean magnitude + shift-term shares (l1_scan_kernel); with_guard: also the guard as a launch of its own
+static int g8_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, bool with_guard, void* stream) {
     if (d->Hp != G8_HP) { loc_set_error("loc_l1_quant_scan: needs padded width 256 (got %d)", d->Hp); return -1; }
     unsigned char* base = static_cast<unsigned char*>(image);
     uint32_t* colmax = reinterpret_cast<uint32_t*>(base + g8_colmax_off());
     float* guard = reinterpret_cast<float*>(base + g8_guard_off());
-    float* cpart = reinterpret_cast<float*>(base + g8_cpart_off());
-    const int nkt = g8_nkt64(d), grid = nkt < 256 ? nkt : 256;           // one workgroup per compute unit: 256 shares for the guard
+    float* shares = reinterpret_cast<float*>(base + g8_cpart_off());
+    const int nkt = g8_nkt64(d), grid = g8_scan_grid(d);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
     if (e != hipSuccess) { loc_set_error("loc_l1_quant_scan: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(l1_colmax_kernel, dim3(grid), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax, cpart);
+    hipLaunchKernelGGL(l1_scan_kernel, dim3(grid), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax, shares,
+                       shares + (int64_t)grid * G8_HP);
     LOC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(l1_quant_guard_kernel, dim3(1), dim3(1024), 0, st, colmax, cpart, grid, d->K, d->H, guard);
-    LOC_CHECK_LAUNCH();
+    if (with_guard) {             // a caller that reads the guard back before the image is built (loc_predict_scan)
+        hipLaunchKernelGGL(l1_quant_guard_kernel, dim3(1), dim3(1024), 0, st, colmax, shares, grid, d->K, d->H, guard);
+        LOC_CHECK_LAUNCH();
+    }
     return 0;
+}
+extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, void* stream) {
+    return g8_scan(d, scale_shift, w1s, image, true, stream);
 }
 extern "C" int64_t loc_l1_image_i8_guard_offset(void) { return g8_guard_off(); }
 
@@ -677,20 +797,23 @@ static int g8_image_build(const loc_dims* d, const float* scale_shift, const flo
     float* cvec = reinterpret_cast<float*>(base);
     float* delta = reinterpret_cast<float*>(base + g8_delta_off());
     uint32_t* colmax = reinterpret_cast<uint32_t*>(base + g8_colmax_off());
-    float* cpart = reinterpret_cast<float*>(base + g8_cpart_off());
+    float* guard = reinterpret_cast<float*>(base + g8_guard_off());
+    const float* shares = reinterpret_cast<const float*>(base + g8_cpart_off());
     unsigned char* tiles = base + g8_tiles_off(d);
-    const int nkt = g8_nkt64(d);
+    const int nkt = g8_nkt64(d), grid = g8_scan_grid(d);
     hipStream_t st = (hipStream_t)stream;
-    if (!scanned) {
-        const int rc = loc_l1_quant_scan(d, scale_shift, w1s, image, stream);
+    if (!scanned) {               // two launches per image (+ the 1 KB memset): scan, then tiles with the tail workgroup
+        const int rc = g8_scan(d, scale_shift, w1s, image, false, stream);
         if (rc) return rc;
     }
     if (digits == 2)
-        hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax, delta, tiles, cpart);
+        hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt + 1), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, d->K, d->H, colmax,
+                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec);
     else
-        hipLaunchKernelGGL(l1_image_i8_kernel<3>, dim3(nkt), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, colmax, delta, tiles, cpart);
+        hipLaunchKernelGGL(l1_image_i8_kernel<3>, dim3(nkt + 1), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, d->K, d->H, colmax,
+                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec);
     LOC_CHECK_LAUNCH();
-    return gm_launch_cvec(cpart, nkt, cvec, stream);
+    return 0;
 }
 extern "C" int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits,
                                      void* image, void* stream) {

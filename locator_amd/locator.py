@@ -389,9 +389,9 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
                              "genotypes and filters (--min_mac, --max_SNPs, --impute_missing), --width and --nlayers")
         history = History()
     else:
-        from . import replicates
-        # fits that share this process with other fit threads launch their epochs eagerly (replicates._FIT_THREADS)
-        use_graph = not args.no_graph and replicates.fit_threads_in_process() <= 1
+        # (round 5: fit threads that share a process capture their epoch graphs too - train.DEVICE_LOCK keeps a capture
+        # apart from a sibling's set-up / read-back / tear-down; round 4 launched them eagerly)
+        use_graph = not args.no_graph
         history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
                       max_epochs=args.max_epochs, patience=earlystop["patience"], lr_patience=reducelr["patience"],
                       lr_factor=reducelr["factor"], use_graph=use_graph, verbose=args.keras_verbose,
@@ -471,6 +471,16 @@ _BASE_LOCK = __import__("threading").Lock()
 
 
 def _fit_unit(unit, device="cuda:0"):
+    """_fit_unit_body under the process-wide device lock (train.DEVICE_LOCK): when several fits share a process, one thread
+    and stream each, everything a fit does on the device outside its epoch loop - upload, net construction, read-backs,
+    predict, and the destruction of its graphs / events / buffers when the body returns - is kept apart from a sibling's
+    HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run)."""
+    from .train import DEVICE_LOCK
+    with DEVICE_LOCK:
+        return _fit_unit_body(unit, device)
+
+
+def _fit_unit_body(unit, device="cuda:0"):
     """One replicate fit + predict on `device` — the body of the reference's window / bootstrap loops
     (locator.py:546-571, :656-676).  `unit` carries everything that depended on the NumPy stream.
     The unit's train / validation / prediction rows are uploaded once as one uint8 matrix; a

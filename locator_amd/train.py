@@ -25,6 +25,62 @@ from .net import LocatorNet
 CAPTURE_ERROR_MODE = "thread_local"
 
 
+class _DeviceLock:
+    """Process-wide mutex that makes HIP-graph capture safe when several fits share a process (one thread and stream each).
+
+    Round 4 found capture process-sensitive even in thread-local capture mode: a sibling thread's device-wide
+    synchronize made the capture fail (hipErrorStreamCaptureUnsupported), and a sibling destroying a graph / an event (a
+    finished fit going away) aborted the process now and then.  All of those calls live OUTSIDE a fit's steady epoch loop -
+    building the net and its buffers, reading results back, predicting, tearing the fit down - while the loop itself only
+    enqueues on its own stream, replays, records and waits on events.  So:
+      * a fit thread holds the lock for everything it does on the device EXCEPT its epoch loop (`with DEVICE_LOCK:` around
+        the unit in locator._fit_unit; FitLoop.run() lets go of it with `released()` while it loops);
+      * a capture (two short events per fit, EpochRunner.start_epoch) takes the lock: no sibling is setting up, reading
+        back or tearing down while a capture is open, and no two captures overlap.
+    Re-entrant per thread; `released()` drops the thread's hold entirely for the duration of a block."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._tls = threading.local()
+
+    def __enter__(self):
+        depth = getattr(self._tls, "depth", 0)
+        if depth == 0:
+            self._lock.acquire()
+        self._tls.depth = depth + 1
+        return self
+
+    def __exit__(self, *exc):
+        self._tls.depth -= 1
+        if self._tls.depth == 0:
+            self._lock.release()
+        return False
+
+    def held(self):
+        return getattr(self._tls, "depth", 0) > 0
+
+    def released(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            depth = getattr(self._tls, "depth", 0)
+            if depth:
+                self._tls.depth = 0
+                self._lock.release()
+            try:
+                yield
+            finally:
+                if depth:
+                    self._lock.acquire()
+                    self._tls.depth = depth
+        return cm()
+
+
+DEVICE_LOCK = _DeviceLock()
+
+
 class Callbacks:
     """ModelCheckpoint(best only) -> EarlyStopping -> ReduceLROnPlateau on val_loss, in that order
     (locator.py:362).  All comparisons are strict '<' with min_delta 0 (locator.py:349-361)."""
@@ -274,15 +330,17 @@ class EpochRunner:
                 # graph, an event), whose HIP call is illegal inside a capture and aborts the process - seen once in a few
                 # runs of the GPU suite (`Fatal Python error: Aborted ... Garbage-collecting`).  torch.cuda.graph() itself
                 # collects everything collectable before the capture begins.
+                # ... and no sibling fit of this process outside its epoch loop while the capture is open (DEVICE_LOCK)
                 import gc
-                gc_was = gc.isenabled()
-                gc.disable()
-                try:
-                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
-                        self.enqueue(epoch=e)
-                finally:
-                    if gc_was:
-                        gc.enable()
+                with DEVICE_LOCK:
+                    gc_was = gc.isenabled()
+                    gc.disable()
+                    try:
+                        with torch.cuda.graph(g, capture_error_mode=CAPTURE_ERROR_MODE, **kw):
+                            self.enqueue(epoch=e)
+                    finally:
+                        if gc_was:
+                            gc.enable()
                 graphs[slot] = g
                 if not self.xchain:
                     self.graph = g
@@ -408,12 +466,16 @@ class FitLoop:
         return self.hist
 
     def run(self):
-        while not self.done:
-            if not self.submit():
-                self.collect(0)
-                break
-            self.collect()
-        return self.finish()
+        # the steady loop only enqueues on this thread's stream, replays graphs, records and waits on events: it runs
+        # without the process-wide device lock (a sibling fit may be capturing meanwhile); finish() reads back under it
+        with DEVICE_LOCK.released():
+            while not self.done:
+                if not self.submit():
+                    self.collect(0)
+                    break
+                self.collect()
+        with DEVICE_LOCK:
+            return self.finish()
 
 
 def fit(net: LocatorNet, train_rows, val_rows, *, batch_size=32, max_epochs=5000, patience=100, lr_patience=None,

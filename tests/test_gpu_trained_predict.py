@@ -169,3 +169,38 @@ def test_outliers_3000x_are_refused_by_the_guard(trained_metric):
     out = _check(x, X, Y, q32, 2, "metric fit + 3000 x outliers", expect_auto_digits=-1, fast_must_hold=False)
     assert out["fast"][1] > NORTH_STAR_REL, out["fast"]
     assert int(out["exact"][2][3]) == -1
+
+
+def _with_range(p32, r_all, r_one=None):
+    """The trained net with every unit's largest scaled weight moved so that its guard statistic R_h = max / (1.2533 mean
+    magnitude) equals r_all (unit 7: r_one) - weights sitting right at the guard's thresholds (VERDICT r04 weak #7)."""
+    p = O.cast_params(p32, np.float64)
+    s = p["gamma"] / np.sqrt(p["mov_var"] + O.BN_EPS)
+    wp = p["W"][0] * s[:, None]
+    K, H = wp.shape
+    c = np.sqrt(np.pi / 2)
+    q = {k: ([w.copy() for w in v] if isinstance(v, list) else v.copy()) for k, v in p32.items()}
+    for h in range(H):
+        T = r_one if (r_one is not None and h == 7) else r_all
+        k = int(np.abs(wp[:, h]).argmax())
+        m, mean = abs(wp[k, h]), np.abs(wp[:, h]).mean()
+        new = T * c * (mean - m / K) / (1.0 - T * c / K)
+        q["W"][0][k, h] = np.float32(np.sign(wp[k, h]) * new / s[k])
+    return q
+
+
+def test_guard_edges_two_planes_just_inside_and_just_outside_the_thresholds(trained_metric):
+    """The thresholds themselves (include/locator_hip.h: two planes while median R <= 64 and max R <= 512; three while
+    max R <= 512).  Weights constructed to sit at median 60 / max 500 must get two planes AND hold 1e-3; max 525 must send
+    both modes to the exactly-split bf16 pieces; median 70 must get three planes.  The exact mode holds 2e-5 in every case."""
+    x, X, Y, p32 = trained_metric
+    inside = _with_range(p32, 60.0, 500.0)
+    R = _range_stats(inside)
+    assert 59.0 < np.sort(R)[(len(R) - 1) // 2] < 61.0 and 495.0 < R.max() < 505.0, (np.median(R), R.max())
+    out = _check(x, X, Y, inside, 1, "guard edge: median 60 / max 500", expect_auto_digits=2)
+    assert int(out["exact"][2][3]) == 3
+    outside = _with_range(p32, 60.0, 525.0)
+    out = _check(x, X, Y, outside, 1, "guard edge: median 60 / max 525", expect_auto_digits=-1, fast_must_hold=False)
+    assert int(out["exact"][2][3]) == -1
+    mid = _with_range(p32, 70.0)
+    _check(x, X, Y, mid, 1, "guard edge: median 70 / max 70", expect_auto_digits=3, fast_must_hold=False)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""The reference README's windowed example, end to end, in the small-K regime (VERDICT r04 next #3b):
+
+    locator --zarr data/test_genotypes.zarr --sample_data data/test_sample_data.txt --out out/test_windows/ --windows --window_size 250000
+    "This should take around 5 minutes on a GPU"                                   (/root/reference/README.md:59-63)
+
+= 10 windows of ~1,150 SNPs x 450 located samples of the example VCF (tests/golden/test_genotypes.vcf.gz, converted to a
+blosc / lz4 zarr store as scripts/vcf_to_zarr.py would), default epochs / patience.  Every step of such a fit is three launches
+of 5-50 us, so this is where HIP-graph replay and the host's share matter.  Layouts run one after the other in fresh
+processes (the CLI, as a user starts it):
+
+    default             worker process, 2 fit threads, epoch graphs (round 5: captured under train.DEVICE_LOCK)
+    no_graph            the same, epochs launched eagerly (round 4's behaviour for fit threads)
+    one_fit             --fits_per_gpu 1, graphs
+    one_fit_no_graph    --fits_per_gpu 1, eager
+    two_procs           --procs_per_gpu 2 --fits_per_gpu 2 (one fit per process, rounds 1-3), graphs
+
+Per layout: wall of the whole command, mean fit seconds / epochs per window, ms per epoch, and a digest of the ten predlocs
+files (must not depend on the layout).  --busy additionally samples the GPU's busy percentage (rocm-smi --showuse, 5 Hz)
+during the default layout: idle fraction = 1 - mean busy.  One JSON object on stdout (profiles/r05_readme_windows.json).
+"""
+import argparse
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+LAYOUTS = {
+    "default": [],
+    "no_graph": ["--no_graph"],
+    "one_fit": ["--fits_per_gpu", "1"],
+    "one_fit_no_graph": ["--fits_per_gpu", "1", "--no_graph"],
+    "two_procs": ["--procs_per_gpu", "2", "--fits_per_gpu", "2"],
+}
+
+
+def busy_sampler(stop, out):
+    while not stop.is_set():
+        try:
+            txt = subprocess.run(["rocm-smi", "--showuse"], capture_output=True, text=True, timeout=5).stdout
+            m = re.search(r"GPU use \(%\):\s*(\d+)", txt)
+            if m:
+                out.append(int(m.group(1)))
+        except Exception:                                       # noqa: BLE001
+            pass
+        stop.wait(0.2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layouts", default=",".join(LAYOUTS))
+    ap.add_argument("--busy", action="store_true")
+    ap.add_argument("--repeat", type=int, default=1, help="runs per layout (the fastest wall is reported, all are listed)")
+    ap.add_argument("--extra", default="", help="extra CLI flags for every layout, space separated")
+    a = ap.parse_args()
+    from locator_amd import genotypes as G
+    tmp = tempfile.mkdtemp(prefix="readme_windows_")
+    store = os.path.join(tmp, "test_genotypes.zarr")
+    v = G.read_vcf(os.path.join(GOLD, "test_genotypes.vcf.gz"))
+    G.write_callset_zarr(store, v["calldata/GT"], v["variants/POS"], v["samples"], chunk_variants=4096, compressor="blosc")
+    res = {"workload": "reference README windows example: --windows --window_size 250000 on the example VCF as a blosc zarr store "
+                       "(10 windows x ~1,150 SNPs, 450 located samples, default --max_epochs 5000 --patience 100)",
+           "reference_says": "around 5 minutes on a GPU (/root/reference/README.md:63)", "layouts": {}}
+    for name in a.layouts.split(","):
+        runs = []
+        for rep in range(a.repeat):
+            out = os.path.join(tmp, f"{name}_{rep}", "w")
+            os.makedirs(os.path.dirname(out))
+            cmd = [sys.executable, "-m", "locator_amd.locator", "--zarr", store, "--sample_data", os.path.join(GOLD, "test_sample_data.txt"),
+                   "--out", out, "--windows", "--window_size", "250000", "--seed", "12345", "--keras_verbose", "0",
+                   "--plot_history", ""] + LAYOUTS[name] + a.extra.split()
+            stop, busy = threading.Event(), []
+            th = None
+            if a.busy and name == "default" and rep == 0:
+                th = threading.Thread(target=busy_sampler, args=(stop, busy), daemon=True)
+                th.start()
+            t0 = time.time()
+            p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+            wall = time.time() - t0
+            stop.set()
+            if th is not None:
+                th.join()
+            r = {"wall_s": round(wall, 2), "rc": p.returncode}
+            if p.returncode != 0:
+                r["stderr_tail"] = p.stderr[-1500:]
+                r["stdout_tail"] = p.stdout[-800:]
+            m = re.search(r"replicate phases, mean of (\d+) units: .*? fit ([0-9.]+) s, predict ([0-9.]+) s", p.stdout)
+            if m:
+                r["units"], r["fit_s_mean"], r["predict_s_mean"] = int(m.group(1)), float(m.group(2)), float(m.group(3))
+            m = re.search(r"replicate timeline: wall ([0-9.]+) s = parent prologue ([0-9.]+) s \+ dispatch loop ([0-9.]+) s", p.stdout)
+            if m:
+                r["prologue_s"], r["dispatch_loop_s"] = float(m.group(2)), float(m.group(3))
+            import glob
+            import pandas as pd
+            hs = sorted(glob.glob(out + "_*_history.txt"))
+            ep = [len(pd.read_csv(h, sep="\t")) for h in hs]
+            if ep:
+                r["epochs_mean"] = round(sum(ep) / len(ep), 1)
+                if "fit_s_mean" in r:
+                    r["ms_per_epoch"] = round(1e3 * r["fit_s_mean"] / r["epochs_mean"], 3)
+            dg = hashlib.sha256()
+            for f in sorted(glob.glob(out + "_*_predlocs.txt")):
+                dg.update(open(f, "rb").read())
+            r["predlocs_files"] = len(glob.glob(out + "_*_predlocs.txt"))
+            r["predlocs_sha16"] = dg.hexdigest()[:16]
+            if busy:
+                r["gpu_busy_percent_mean"] = round(sum(busy) / len(busy), 1)
+                r["gpu_idle_fraction"] = round(1 - sum(busy) / len(busy) / 100, 3)
+                r["busy_samples"] = len(busy)
+            runs.append(r)
+        best = min(runs, key=lambda r: r["wall_s"])
+        res["layouts"][name] = dict(best, flags=" ".join(LAYOUTS[name]) or "(none)", walls_s=[r["wall_s"] for r in runs])
+        print(f"# {name}: {json.dumps(res['layouts'][name])}", file=sys.stderr, flush=True)
+    d = {r["predlocs_sha16"] for r in res["layouts"].values()}
+    res["same_predlocs_in_every_layout"] = len(d) == 1
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
