@@ -100,9 +100,11 @@ typedef struct loc_tuning {
     int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
-    int stack_rows;       /* hidden stack of a many-row predict: 0 = default: 32 rows per workgroup on the fp32 matrix pipe from
-                             loc_stack_rows_min_rows() rows per chunk, 2 rows per workgroup on the vector ALU below; 1 = the
-                             matrix-pipe form for every chunk; -1 = never (measurement switch)                              */
+    int stack_rows;       /* hidden stack of a many-row predict: 0 = default: from loc_stack_rows_min_rows() (1280) rows per chunk
+                             the fp32 matrix pipe - 16 or 32 rows per workgroup, whichever needs less rounds x time per round
+                             on this device's compute units (16-row tiles up to 4096 rows and at 8193..12288 on 256 units) -
+                             and 2 rows per workgroup on the vector ALU below; 1 = the 32-row matrix-pipe form for every
+                             chunk; 2 = the 16-row form for every chunk; -1 = never (measurement switch)                    */
     int gemm_reduce;      /* many-row predicts on the int8 pipe: 0 = default: the SNP-group sum + shift + b1 + ELU of the layer-1
                              GEMM is its own launch (l1_gemm_reduce_kernel); 1 = it happens in the input stage of the
                              hidden-stack launch instead (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial: same
@@ -302,7 +304,8 @@ int loc_l1_forward_gemm(const uint8_t* X, int64_t x_pitch, const int32_t* rows, 
 /* The same contraction on the INT8 matrix pipe (l1_gemm_i8.hip), for genotypes known to lie in 0..127 (x_max): a
  * genotype is an int8 as it stands, so the row operand is never widened; each weight s_k*W1[k][h] is carried as
  * `digits` base-256 signed digits of a fixed-point number scaled per unit by a power of two chosen from the unit's
- * largest weight (loc_l1_image_i8_build runs the max pass, then writes the digit planes and the shift term).  Products and
+ * largest weight (loc_l1_image_i8_build runs the scan pass - per-unit max, mean magnitude and shift term - then writes the
+ * digit planes; one extra workgroup of that second launch turns the scan's shares into the guard and the shift vector).  Products and
  * sums are exact integers: 3 digits = 24 bits against the unit's largest weight (no worse than fp32 accumulation
  * rounding), 2 digits = 16 bits.  Refuses x_max outside 1..127 and SNP groups long enough to overflow int32
  * (x_max * 128 * SNPs per group >= 2^31).  Other arguments as loc_l1_forward_gemm. */
@@ -318,6 +321,10 @@ int loc_l1_image_i8_build(const loc_dims* d, const float* scale_shift, const flo
  * must hold a scan of the same weights and scale/shift). */
 int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, const float* w1s, void* image, void* stream);
 int64_t loc_l1_image_i8_guard_offset(void);
+/* Byte offset of the digit-plane tiles inside `image` (they follow the header: shift vector, per-unit step, per-unit max,
+ * guard, and the scan's per-workgroup shares); tile (64-SNP block b, plane p) = 16 KB at offset + (b * digits + p) * 16384,
+ * laid out [16-SNP chunk][unit][16 SNPs] int8.  For tools and tests that decode an image. */
+int64_t loc_l1_image_i8_tiles_offset(const loc_dims* d);
 int loc_l1_image_i8_build_scanned(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
                                   void* stream);
 int loc_l1_forward_gemm_i8(const uint8_t* X, int64_t x_pitch, const int32_t* rows, int n, const loc_dims* d,
@@ -427,9 +434,11 @@ int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t gro
                                    const float* Y, float* yhat, float* dist, int rows_form, void* stream);
 /* Both inference entry points take MANY rows (>= loc_stack_rows_min_rows(), padded width 256) through stack_rows.hip: 32 rows
  * per workgroup on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: fp32 products and sums, the weights streamed once per 32
- * rows) instead of 2 rows per workgroup on the vector ALU.  rows_form (loc_stack_forward_eval_form /
- * loc_stack_forward_eval_partial; loc_tuning.stack_rows in loc_predict): 0 = by row count, 1 = always where supported,
- * -1 = never.  Same arithmetic, different summation order: predictions agree to fp32 round-off (tests/test_gpu_stack_rows.py). */
+ * rows), or 16 rows per workgroup (v_mfma_f32_16x16x4_f32) where 32-row tiles would leave compute units idle (up to 4096
+ * rows on 256 compute units, and 8193..12288), instead of 2 rows per workgroup on the vector ALU.  rows_form (loc_stack_forward_eval_form /
+ * loc_stack_forward_eval_partial; loc_tuning.stack_rows in loc_predict): 0 = by row count, 1 = always the 32-row form where
+ * supported, 2 = always the 16-row form, -1 = never.  Same arithmetic, different summation order: predictions agree to fp32
+ * round-off (tests/test_gpu_stack_rows.py). */
 int loc_stack_rows_supported(int Hp, int L);
 int loc_stack_rows_min_rows(void);
 int loc_stack_forward_eval_form(const float* a1, const float* Wh, const float* bh, const float* wa, const float* ba,

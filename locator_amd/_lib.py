@@ -95,6 +95,7 @@ SIGNATURES = {
     "loc_l1_image_i8_build": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_l1_quant_scan": (C.c_int, [C.POINTER(Dims), vp, vp, vp, vp]),
     "loc_l1_image_i8_guard_offset": (C.c_int64, []),
+    "loc_l1_image_i8_tiles_offset": (C.c_int64, [C.POINTER(Dims)]),
     "loc_l1_image_i8_build_scanned": (C.c_int, [C.POINTER(Dims), vp, vp, C.c_int, vp, vp]),
     "loc_predict_scan": (C.c_int, [C.POINTER(Net), vp]),
     "loc_l1_forward_gemm_i8_partial": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.POINTER(Dims), vp, C.c_int, C.c_int, vp,

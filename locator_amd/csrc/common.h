@@ -114,10 +114,10 @@ int gm_launch_cvec(const float* cpart, int nkt64, float* cvec8, void* stream);
 int gm_launch_reduce(const float* partial, int G, int64_t MH, const float* cvec8, const float* b1, float* a1,
                      void* stream);
 
-// stack_rows.hip: the hidden stack + heads for many rows on the fp32 matrix pipe (32 rows per workgroup)
+// stack_rows.hip: the hidden stack + heads for many rows on the fp32 matrix pipe (32 or 16 rows per workgroup: tile_rows, 0 = by row count)
 int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8, const float* rd_b1,
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
-                   int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream);
+                   int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, int tile_rows, void* stream);
 extern "C" int loc_stack_rows_min_rows(void);
 extern "C" int loc_stack_rows_supported(int Hp, int L);
 

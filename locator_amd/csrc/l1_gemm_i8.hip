@@ -22,7 +22,7 @@
 //   l1_image_i8_kernel   W1S (fp32, swizzled) x BN scale -> HBM image of digit planes, one 16 KB tile per (64-SNP block,
 //                        digit plane), laid out [16-SNP chunk c][unit n][16 SNPs]: a wave's MFMA B operand for one
 //                        32-SNP step is two contiguous 512-byte runs.  Plane 0 is the most significant digit.  One extra
-//                        workgroup (g8_tail) turns the scan's shares into the guard and the shift vector meanwhile.
+//                        workgroup (g8_guard_body) turns the scan's shares into the guard and the shift vector meanwhile.
 //   l1_gemm_i8_kernel    workgroup = 8 waves on a 128-row x 256-unit tile; the SNP range is split over groups, group g
 //                        owning a CONTIGUOUS run of pairs of 64-SNP blocks.  A wave owns 32 units and ALL 128 rows: its
 //                        digit fragments go HBM/L2 -> VGPRs (12 fragments = 1.5 pairs in flight, saddr-form requests),
@@ -60,8 +60,8 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 // Workgroup b walks the 64-SNP blocks b, b + grid, ...; one atomicMax per unit and workgroup at the end (a few hundred
 // workgroups, not one per block: the atomics all hit the same 256 words).  colmax[n] = max |s_k W1[k][n]| as the bit pattern
 // of a non-negative float: the maximum is order-independent, so the result is deterministic.
-// The same pass also leaves two shares per workgroup, added up in workgroup order by g8_tail (the image kernel's extra
-// workgroup) or by l1_quant_guard_kernel:
+// The same pass also leaves two shares per workgroup, added up in workgroup order by g8_guard_body (the image
+// kernel's extra workgroup, or l1_quant_guard_kernel):
 //   sumabs_part[workgroup][n]  its share of sum_k |w'|: the unit's TYPICAL weight, against which its largest weight decides
 //                              how many digit planes the weights need (dynamic range guard below).  The mean magnitude, not
 //                              the rms: one weight 3000 x the rest moves the rms of 100,000 weights by 10 x (max / rms can
@@ -69,59 +69,41 @@ typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 //                              case through) but the mean by 3 %.
 //   csum_part[workgroup][n]    its share of the shift term sum_k t_k W1[k][n] (round 5: it used to be a by-product of the
 //                              image kernel plus a launch of l1_image_cvec_kernel; here it costs one FMA per weight)
-// Addressing (round 5): a lane reads 16 bytes = the four units 4 c .. 4 c + 3 of ONE SNP (W1S keeps them adjacent), the
-// four lanes of a quad take SNPs kl = 4 j + c4 - 8 requests per thread and 32-SNP tile instead of 32 four-byte ones - and
-// the per-unit statistics of the quad's four lanes meet once, at the end, in a fixed order.
+// Thread = unit n (the addressing of l1_image_kernel): four-byte loads, the BatchNorm scale / shift of a SNP are wave-uniform
+// (scalar loads).  A 16-byte-per-lane form (a quad's lanes taking the four units of one SNP each, statistics exchanged at
+// the end) was built in round 5 and measured SLOWER: 30.4 us against 19.4 for the same 102 MB - its scale / shift loads are
+// lane-dependent vector loads, 16 more per 32-SNP tile.
 __global__ __launch_bounds__(G8_HP) void l1_scan_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
                                                         int Kp, int nkt64, uint32_t* __restrict__ colmax,
                                                         float* __restrict__ sumabs_part, float* __restrict__ csum_part) {
     constexpr int nht = G8_HP / 32;
     const int n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
-    float mx[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float mx = 0.f, ss = 0.f, cs = 0.f;
     for (int kt64 = blockIdx.x; kt64 < nkt64; kt64 += gridDim.x) {
 #pragma unroll
         for (int h32 = 0; h32 < 2; ++h32) {
             const int kt32 = 2 * kt64 + h32;
             if (kt32 * 32 < Kp) {
-                const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128;
-                f32x4 v[8];
-                float sc[8], sh[8];
+                const float* src = w1s + ((int64_t)(kt32 * nht + ht) * 4 + q) * 256 + hi * 128 + c4;
+                float m4[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {0.f, 0.f, 0.f, 0.f}, c4s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kl = 4 * j + c4;
-                    v[j] = *reinterpret_cast<const f32x4*>(src + kl * 4);
-                    sc[j] = ss4[kt32 * 32 + kl];
-                    sh[j] = ss4[Kp + kt32 * 32 + kl];
+                for (int kl = 0; kl < 32; ++kl) {
+                    const float wr = src[kl * 4];
+                    const float w = wr * ss4[kt32 * 32 + kl];
+                    m4[kl & 3] = fmaxf(m4[kl & 3], fabsf(w));
+                    s4[kl & 3] += fabsf(w);
+                    c4s[kl & 3] = fmaf(ss4[Kp + kt32 * 32 + kl], wr, c4s[kl & 3]);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float a = fabsf(v[j][u] * sc[j]);
-                        mx[u] = fmaxf(mx[u], a);
-                        ss[u] += a;
-                        cs[u] = fmaf(sh[j], v[j][u], cs[u]);
-                    }
+                mx = fmaxf(mx, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+                ss += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                cs += (c4s[0] + c4s[1]) + (c4s[2] + c4s[3]);
             }
         }
     }
-    // the quad's four lanes hold the same four units over different SNPs: (lane 0 + lane 1) + (lane 2 + lane 3), then lane c4
-    // keeps unit c4 = its own
-    float mxo = 0.f, sso = 0.f, cso = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        float m = fmaxf(mx[u], __shfl_xor(mx[u], 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        float a = ss[u] + __shfl_xor(ss[u], 1);
-        a = a + __shfl_xor(a, 2);
-        float c = cs[u] + __shfl_xor(cs[u], 1);
-        c = c + __shfl_xor(c, 2);
-        if (u == c4) { mxo = m; sso = a; cso = c; }
-    }
-    if (mxo > 0.f) atomicMax(colmax + n, fbits(mxo));
-    sumabs_part[(int64_t)blockIdx.x * G8_HP + n] = sso;
-    csum_part[(int64_t)blockIdx.x * G8_HP + n] = cso;
+    if (mx > 0.f) atomicMax(colmax + n, fbits(mx));
+    sumabs_part[(int64_t)blockIdx.x * G8_HP + n] = ss;
+    csum_part[(int64_t)blockIdx.x * G8_HP + n] = cs;
 }
 
 // Dynamic-range guard of the fixed-point image.  A unit's weights share one power-of-two step delta_h chosen from its
@@ -134,63 +116,87 @@ __global__ __launch_bounds__(G8_HP) void l1_scan_kernel(const float* __restrict_
 // guard[0] = median R over the real units (lower middle value), guard[1] = largest R, guard[2] = digit planes that hold
 // the tolerances of include/locator_hip.h (LOC_GUARD_*): 2, 3, or -1 = not even three (bf16 x 3 pieces: exact for any
 // weights), guard[3] = 3 or -1: the same decision when the caller insists on the exact mode.
-__global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
-                                                              const float* __restrict__ sumabs_part, int nparts, int K, int H,
-                                                              float* __restrict__ guard) {
-    __shared__ __attribute__((aligned(16))) float R[G8_HP];
-    __shared__ __attribute__((aligned(16))) float qs[16][G8_HP];
-    // 1024 threads: thread (q, n4) adds the workgroup shares b = q, q + 16, ... of the four units 4 n4 .. 4 n4 + 3, all at
-    // once, as 16-byte loads: the shares were written by workgroups on every XCD, so each load is a trip to memory, and a
-    // compute unit retires a 4-byte-per-lane load instruction no faster than a 16-byte one (1,024 of them took 10 of this
-    // kernel's 15 us; a single wave per unit walking 512 strided shares one after the other: 127 us).  The sixteen
-    // partial sums of a unit, then the units' statistics, are combined in a fixed order.
-    {
-        const int n4 = threadIdx.x & 63, q = threadIdx.x >> 6;
-        f32x4 a[16];
+// Stage 1 of the guard: share group q (of 16) = workgroup shares b = q, q + 16, ..., q + 240, added by the tree
+// ((e, e + 8), (e, e + 4), (e, e + 2), (e, e + 1)) -> one row of 256 values.  Sixteen 16-byte loads per thread at once: the
+// shares were written by workgroups on every XCD, so each load is a trip to memory, and a compute unit retires a
+// 4-byte-per-lane load instruction no faster than a 16-byte one (1,024 of them took 10 of the guard kernel's 15 us; a single
+// wave per unit walking 512 strided shares one after the other: 127 us; a 256-thread workgroup taking the sixteen groups in
+// four rounds: 35 us - each round pays the full memory latency).
+// 64 threads per group (thread = four units): returns the group's sums of the four units 4 n4 .. 4 n4 + 3.
+__device__ __forceinline__ f32x4 g8_share_group16(const float* __restrict__ part, int q, int n4, int nparts) {
+    f32x4 a[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int b = q + 16 * e;
-            a[e] = b < nparts ? *reinterpret_cast<const f32x4*>(sumabs_part + (int64_t)b * G8_HP + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int w2 = 8; w2 > 0; w2 >>= 1)
-#pragma unroll
-            for (int e = 0; e < w2; ++e) a[e] = a[e] + a[e + w2];
-        *reinterpret_cast<f32x4*>(&qs[q][4 * n4]) = a[0];
+    for (int e = 0; e < 16; ++e) {
+        const int b = q + 16 * e;
+        a[e] = b < nparts ? *reinterpret_cast<const f32x4*>(part + (int64_t)b * G8_HP + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    // (every thread reaches the barriers below; the statistics are the first 256 threads' work)
+#pragma unroll
+    for (int w2 = 8; w2 > 0; w2 >>= 1)
+#pragma unroll
+        for (int e = 0; e < w2; ++e) a[e] = a[e] + a[e + w2];
+    return a[0];
+}
+// The same sums by 256 threads for ONE group: quarter `sub` (= wave) of the workgroup loads e = sub, sub + 4, sub + 8, sub + 12
+// and forms (a[sub] + a[sub + 8]) + (a[sub + 4] + a[sub + 12]) - what the tree above holds in a[sub] after its first two
+// levels - and the four quarters meet in LDS as (x0 + x2) + (x1 + x3): the same bits.
+__device__ __forceinline__ f32x4 g8_share_group4(const float* __restrict__ part, int q, int n4, int sub, int nparts) {
+    f32x4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = q + 16 * (sub + 4 * i);
+        a[i] = b < nparts ? *reinterpret_cast<const f32x4*>(part + (int64_t)b * G8_HP + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return (a[0] + a[2]) + (a[1] + a[3]);
+}
+
+// Stage 2: the sixteen group rows qs[16][256] (LDS or global) -> guard[0..3]; qc non-NULL: cvec8[0][n] = the shift term,
+// cvec8[1..7][n] = 0 (l1_gemm_reduce_kernel adds eight slices).  NT >= 256 threads, the statistics are the first 256's work.
+template <int NT>
+__device__ __forceinline__ void g8_guard_finish(const uint32_t* __restrict__ colmax, const float* qs, const float* qc, int K,
+                                                int H, float* __restrict__ guard, float* __restrict__ cvec8) {
+    __shared__ __attribute__((aligned(16))) float R[G8_HP];
     const int n = threadIdx.x & (G8_HP - 1);
     const bool first = threadIdx.x < G8_HP;
+    if (qc && first) {
+        float cs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cs += qc[q * G8_HP + n];
+        cvec8[n] = cs;
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) cvec8[sl * G8_HP + n] = 0.f;
+    }
     float ss = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ss += qs[q][n];
+    for (int q = 0; q < 16; ++q) ss += qs[q * G8_HP + n];
     const float mx = bitsf(colmax[n]);
     const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
     const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
     if (first) R[n] = r;
     __syncthreads();
     // median by rank counting (256 values): the value with exactly floor((H - 1) / 2) smaller-or-earlier entries.  The
-    // 256 x 256 comparisons are most of this kernel's arithmetic: every thread takes a quarter of the candidates of its unit
-    // (thread (p, n): entries 64 p .. 64 p + 63), the four partial counts meet in LDS
-    __shared__ int rk[4][G8_HP];
+    // 256 x 256 comparisons are most of this part's arithmetic: with 1024 threads every thread takes a quarter of the
+    // candidates of its unit (thread (p, n): entries 64 p .. 64 p + 63), the partial counts meet in LDS
+    constexpr int NP = NT / G8_HP;
+    __shared__ int rk[NP][G8_HP];
     {
         const int p = threadIdx.x >> 8;
-        const f32x4* R4 = reinterpret_cast<const f32x4*>(R) + 16 * p;
+        const f32x4* R4 = reinterpret_cast<const f32x4*>(R) + (64 / NP) * p;
         int cnt = 0;
 #pragma unroll 4
-        for (int j4 = 0; j4 < 16; ++j4) {
+        for (int j4 = 0; j4 < 64 / NP; ++j4) {
             const f32x4 v = R4[j4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int j = 64 * p + 4 * j4 + e;
+                const int j = (256 / NP) * p + 4 * j4 + e;
                 cnt += (j < H && (v[e] < r || (v[e] == r && j < n))) ? 1 : 0;
             }
         }
         rk[p][n] = cnt;
     }
     __syncthreads();
-    const int rank = (rk[0][n] + rk[1][n]) + (rk[2][n] + rk[3][n]);
+    int rank = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) rank += rk[p][n];
     // the largest R: inside each of the first four waves by lane exchanges, then four values through LDS
     __shared__ float red[4];
     float wmax = r;
@@ -210,6 +216,18 @@ __global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __
     }
 }
 
+// the guard as a launch of its own (loc_l1_quant_scan: a caller that reads it back before the image is built): 1024 threads,
+// thread (q, n4) = share group q, units 4 n4 .. 4 n4 + 3
+__global__ __launch_bounds__(1024) void l1_quant_guard_kernel(const uint32_t* __restrict__ colmax,
+                                                              const float* __restrict__ sumabs_part, int nparts, int K, int H,
+                                                              float* __restrict__ guard) {
+    __shared__ __attribute__((aligned(16))) float qs[16 * G8_HP];
+    const int n4 = threadIdx.x & 63, q = threadIdx.x >> 6;
+    *reinterpret_cast<f32x4*>(&qs[q * G8_HP + 4 * n4]) = g8_share_group16(sumabs_part, q, n4, nparts);
+    __syncthreads();
+    g8_guard_finish<1024>(colmax, qs, nullptr, K, H, guard, nullptr);
+}
+
 // delta_h = 2^e with max_k|w'| / delta_h inside the signed-digit range: 127 (256^DT - 1) / 255.
 template <int DT>
 __device__ __forceinline__ float digit_delta(float mx) {
@@ -222,86 +240,54 @@ __device__ __forceinline__ float digit_delta(float mx) {
     return ldexpf(1.f, e);
 }
 
-// The once-per-image leftovers, done by ONE extra workgroup of the image kernel while the others convert tiles (round 5: they
-// used to be two launches, l1_quant_guard_kernel and l1_image_cvec_kernel, 9 + 5 us on the stream): the workgroup shares of
-// the scan are added in workgroup order -> guard[0..3] (as l1_quant_guard_kernel) and cvec8[0][n] = the shift term
-// sum_k t_k W1[k][n], cvec8[1..7][n] = 0 (l1_gemm_reduce_kernel adds eight slices).  256 threads, thread = unit.
-__device__ __forceinline__ void g8_tail(const uint32_t* __restrict__ colmax, const float* __restrict__ sumabs_part,
-                                        const float* __restrict__ csum_part, int nparts, int K, int H,
-                                        float* __restrict__ guard, float* __restrict__ cvec8) {
-    __shared__ __attribute__((aligned(16))) float R[G8_HP];
-    __shared__ float red[4];
-    __shared__ float s_med;
-    const int n = threadIdx.x;
-    float sa[8], ca[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sa[e] = ca[e] = 0.f;
-    int b = 0;
-    for (; b + 8 <= nparts; b += 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sa[e] += sumabs_part[(int64_t)(b + e) * G8_HP + n];
-            ca[e] += csum_part[(int64_t)(b + e) * G8_HP + n];
-        }
-    }
-    for (int e = 0; b < nparts; ++b, ++e) {
-        sa[e] += sumabs_part[(int64_t)b * G8_HP + n];
-        ca[e] += csum_part[(int64_t)b * G8_HP + n];
-    }
-    const float ss = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
-    const float cs = ((ca[0] + ca[1]) + (ca[2] + ca[3])) + ((ca[4] + ca[5]) + (ca[6] + ca[7]));
-    cvec8[n] = cs;
-#pragma unroll
-    for (int sl = 1; sl < 8; ++sl) cvec8[sl * G8_HP + n] = 0.f;
-    const float mx = bitsf(colmax[n]);
-    const float typ = 1.2533141f * ss / (float)K;           // sqrt(pi / 2) x mean magnitude = the rms of a Gaussian bulk
-    const float r = (n < H && typ > 0.f) ? mx / typ : 0.f;
-    R[n] = r;
-    __syncthreads();
-    // median by rank counting: the value with exactly floor((H - 1) / 2) smaller-or-earlier entries
-    int rank = 0;
-    const f32x4* R4 = reinterpret_cast<const f32x4*>(R);
-#pragma unroll 4
-    for (int j4 = 0; j4 < G8_HP / 4; ++j4) {
-        const f32x4 v = R4[j4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = 4 * j4 + e;
-            rank += (j < H && (v[e] < r || (v[e] == r && j < n))) ? 1 : 0;
-        }
-    }
-    float wmax = r;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-    if ((n & 63) == 0) red[n >> 6] = wmax;
-    if (n < H && rank == (H - 1) / 2) s_med = r;
-    __syncthreads();
-    if (n == 0) {
-        const float rmed = s_med, rmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        guard[0] = rmed;
-        guard[1] = rmax;
-        const float exact = rmax <= LOC_GUARD_EXACT_MAX ? 3.f : -1.f;
-        guard[2] = (rmed <= LOC_GUARD_FAST_MEDIAN && rmax <= LOC_GUARD_FAST_MAX) ? 2.f : exact;
-        guard[3] = exact;
-    }
-}
-
 // tiles[(kt64*DT + p)][c][n][e] = digit plane p (0 = most significant) of q = rint(s_k W1[k][n] / delta_n),
-// k = kt64*64 + c*16 + e;  delta[n] written by the first tile workgroup.  Workgroup 0 is g8_tail; workgroup 1 + kt64 converts
-// 64-SNP block kt64.
+// k = kt64*64 + c*16 + e;  delta[n] written by the first tile workgroup.  Workgroup G8_TAIL_WGS + kt64 converts 64-SNP block
+// kt64 (thread = unit).  The first G8_TAIL_WGS = 16 workgroups do the once-per-image leftovers meanwhile (round 5: they used
+// to be two launches, l1_quant_guard_kernel and l1_image_cvec_kernel, 9 + 5 us on the stream): workgroup q adds share group q
+// of the scan (sum |w'| and the shift term) into tail_rows[q] / tail_rows[16 + q], publishes it (agent-scope release, then a
+// ticket on *tail_ticket), and the one that draws the last ticket turns the sixteen rows into guard[0..3] and cvec8 - the
+// same association of every sum as l1_quant_guard_kernel.  Measured on the way: ONE leftover workgroup with 512 four-byte
+// loads per thread took longer than all the tiles together (71 us per image instead of 60); the same workgroup with the
+// sixteen groups in four rounds of 16-byte loads 35 us (image kernel 38.7 us); tiles by 1024-thread workgroups (so that one
+// of them could be the 1024-thread guard): 29.8 us against 25.8.
+#define G8_TAIL_WGS 16
 template <int DT>
 __global__ __launch_bounds__(G8_HP) void l1_image_i8_kernel(const float* __restrict__ w1s, const float* __restrict__ ss4,
-                                                            int Kp, int K, int H, const uint32_t* __restrict__ colmax,
+                                                            int Kp, int nkt64, int K, int H, const uint32_t* __restrict__ colmax,
                                                             float* __restrict__ delta, unsigned char* __restrict__ tiles,
                                                             const float* __restrict__ sumabs_part,
                                                             const float* __restrict__ csum_part, int nparts,
-                                                            float* __restrict__ guard, float* __restrict__ cvec8) {
-    if (blockIdx.x == 0) {
-        g8_tail(colmax, sumabs_part, csum_part, nparts, K, H, guard, cvec8);
+                                                            float* __restrict__ guard, float* __restrict__ cvec8,
+                                                            float* __restrict__ tail_rows, unsigned* __restrict__ tail_ticket) {
+    if (blockIdx.x < G8_TAIL_WGS) {
+        __shared__ __attribute__((aligned(16))) float xs[2][4][G8_HP];
+        __shared__ unsigned last;
+        const int q = blockIdx.x, n4 = threadIdx.x & 63, sub = threadIdx.x >> 6;
+        *reinterpret_cast<f32x4*>(&xs[0][sub][4 * n4]) = g8_share_group4(sumabs_part, q, n4, sub, nparts);
+        *reinterpret_cast<f32x4*>(&xs[1][sub][4 * n4]) = g8_share_group4(csum_part, q, n4, sub, nparts);
+        __syncthreads();
+        {
+            const int n = threadIdx.x;
+            tail_rows[q * G8_HP + n] = (xs[0][0][n] + xs[0][2][n]) + (xs[0][1][n] + xs[0][3][n]);
+            tail_rows[(16 + q) * G8_HP + n] = (xs[1][0][n] + xs[1][2][n]) + (xs[1][1][n] + xs[1][3][n]);
+        }
+        // publish, then take a ticket (cdna_hip_programming.md, the in-launch split-K ending: drain, barrier, ONE agent-scope
+        // release by one lane, the wait restated after it, relaxed ticket; the last arriver acquires once)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned k = __hip_atomic_fetch_add(tail_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (k % G8_TAIL_WGS == G8_TAIL_WGS - 1) ? 1u : 0u;      // (the count is never reset: sixteen tickets per image)
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (last) g8_guard_finish<G8_HP>(colmax, tail_rows, tail_rows + 16 * G8_HP, K, H, guard, cvec8);
         return;
     }
     constexpr int nht = G8_HP / 32;
-    const int kt64 = blockIdx.x - 1, n = threadIdx.x;
+    const int kt64 = blockIdx.x - G8_TAIL_WGS, n = threadIdx.x;
     const int ht = n >> 5, hl = n & 31, q = hl >> 3, hi = (hl >> 2) & 1, c4 = hl & 3;
     const float* scale = ss4;
     const float dl = digit_delta<DT>(bitsf(colmax[n]));
@@ -746,16 +732,20 @@ static int g8_nkt64(const loc_dims* d) { return ((d->Kp + G8_BK - 1) / G8_BK + 1
 
 extern "C" int loc_l1_gemm_i8_supported(int Hp, int digits) { return Hp == G8_HP && (digits == 2 || digits == 3); }
 
-// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][guard: Hp floats, 4 used][shares: 2*grid*Hp floats][tiles],
-// 1 KB aligned sections; shares = the scan's per-workgroup sums (sum |w'| first, then the shift term), grid = g8_scan_grid.
+// image = [cvec8: 8*Hp floats][delta: Hp floats][colmax: Hp uints][guard: Hp floats: 4 used + the tail ticket at word 64]
+// [shares: 2*grid*Hp floats][tail rows: 32*Hp floats][tiles], 1 KB aligned sections; shares = the scan's per-workgroup sums
+// (sum |w'| first, then the shift term), grid = g8_scan_grid; the tail rows / ticket belong to the image kernel's leftover
+// workgroups (the ticket is zeroed by the scan's memset together with colmax and the guard, and counts modulo 16 after that:
+// sixteen tickets per image).
 static int64_t g8_delta_off() { return 8 * G8_HP * 4; }
 static int64_t g8_colmax_off() { return g8_delta_off() + G8_HP * 4; }
 static int64_t g8_guard_off() { return g8_colmax_off() + G8_HP * 4; }
 static int64_t g8_cpart_off() { return g8_guard_off() + G8_HP * 4; }
 static int g8_scan_grid(const loc_dims* d) { const int nkt = g8_nkt64(d); return nkt < 256 ? nkt : 256; }   // one workgroup per compute unit
-static int64_t g8_tiles_off(const loc_dims* d) {
-    return (g8_cpart_off() + (int64_t)2 * g8_scan_grid(d) * G8_HP * 4 + 1023) / 1024 * 1024;
-}
+// [shares: 2 * grid rows][tail rows: 32], rows of Hp floats; the tail ticket is word 64 of the guard section
+static int64_t g8_tail_rows_off(const loc_dims* d) { return g8_cpart_off() + (int64_t)2 * g8_scan_grid(d) * G8_HP * 4; }
+static int64_t g8_tail_ticket_off() { return g8_guard_off() + 64 * 4; }
+static int64_t g8_tiles_off(const loc_dims* d) { return (g8_tail_rows_off(d) + (int64_t)32 * G8_HP * 4 + 1023) / 1024 * 1024; }
 extern "C" int64_t loc_l1_image_i8_bytes(const loc_dims* d, int digits) {
     if (!loc_l1_gemm_i8_supported(d->Hp, digits)) return 0;
     return g8_tiles_off(d) + (int64_t)g8_nkt64(d) * digits * G8_TILE;
@@ -770,7 +760,7 @@ static int g8_scan(const loc_dims* d, const float* scale_shift, const float* w1s
     float* shares = reinterpret_cast<float*>(base + g8_cpart_off());
     const int nkt = g8_nkt64(d), grid = g8_scan_grid(d);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(colmax, 0, G8_HP * 4, st);
+    hipError_t e = hipMemsetAsync(colmax, 0, 2 * G8_HP * 4, st);      // colmax and the guard section behind it (with the tail ticket)
     if (e != hipSuccess) { loc_set_error("loc_l1_quant_scan: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(l1_scan_kernel, dim3(grid), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, colmax, shares,
                        shares + (int64_t)grid * G8_HP);
@@ -785,6 +775,7 @@ extern "C" int loc_l1_quant_scan(const loc_dims* d, const float* scale_shift, co
     return g8_scan(d, scale_shift, w1s, image, true, stream);
 }
 extern "C" int64_t loc_l1_image_i8_guard_offset(void) { return g8_guard_off(); }
+extern "C" int64_t loc_l1_image_i8_tiles_offset(const loc_dims* d) { return g8_tiles_off(d); }
 
 static int g8_image_build(const loc_dims* d, const float* scale_shift, const float* w1s, int digits, void* image,
                           bool scanned, void* stream) {
@@ -799,6 +790,8 @@ static int g8_image_build(const loc_dims* d, const float* scale_shift, const flo
     uint32_t* colmax = reinterpret_cast<uint32_t*>(base + g8_colmax_off());
     float* guard = reinterpret_cast<float*>(base + g8_guard_off());
     const float* shares = reinterpret_cast<const float*>(base + g8_cpart_off());
+    float* tail_rows = reinterpret_cast<float*>(base + g8_tail_rows_off(d));
+    unsigned* tail_ticket = reinterpret_cast<unsigned*>(base + g8_tail_ticket_off());
     unsigned char* tiles = base + g8_tiles_off(d);
     const int nkt = g8_nkt64(d), grid = g8_scan_grid(d);
     hipStream_t st = (hipStream_t)stream;
@@ -807,11 +800,11 @@ static int g8_image_build(const loc_dims* d, const float* scale_shift, const flo
         if (rc) return rc;
     }
     if (digits == 2)
-        hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt + 1), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, d->K, d->H, colmax,
-                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec);
+        hipLaunchKernelGGL(l1_image_i8_kernel<2>, dim3(nkt + G8_TAIL_WGS), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, d->K, d->H, colmax,
+                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec, tail_rows, tail_ticket);
     else
-        hipLaunchKernelGGL(l1_image_i8_kernel<3>, dim3(nkt + 1), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, d->K, d->H, colmax,
-                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec);
+        hipLaunchKernelGGL(l1_image_i8_kernel<3>, dim3(nkt + G8_TAIL_WGS), dim3(G8_HP), 0, st, w1s, scale_shift, d->Kp, nkt, d->K, d->H, colmax,
+                           delta, tiles, shares, shares + (int64_t)grid * G8_HP, grid, guard, cvec, tail_rows, tail_ticket);
     LOC_CHECK_LAUNCH();
     return 0;
 }

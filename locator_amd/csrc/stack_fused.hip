@@ -394,11 +394,12 @@ static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, in
                           const float* rd_b1, const float* Wh, const float* bh, const float* wa, const float* ba,
                           const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows, const float* Y,
                           float* yhat, float* dist, void* stream, int rows_form = 0) {
-    // many rows: 32 rows per workgroup on the fp32 matrix pipe (stack_rows.hip) instead of 2 rows per workgroup on the
-    // vector ALU; rows_form: 0 = by row count, 1 = always (where supported), -1 = never (measurement / tests)
+    // many rows: 32 or 16 rows per workgroup on the fp32 matrix pipe (stack_rows.hip) instead of 2 rows per workgroup on the
+    // vector ALU; rows_form: 0 = by row count, 1 = always the 32-row form (where supported), 2 = always the 16-row form,
+    // -1 = never (measurement / tests)
     if (rows_form >= 0 && loc_stack_rows_supported(Hp, L) && (rows_form > 0 || n_b >= loc_stack_rows_min_rows()))
         return sr_eval_launch(a1, rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist,
-                              stream);
+                              rows_form == 1 ? 32 : rows_form == 2 ? 16 : 0, stream);
     const loc_tuning* tune = nullptr;
     const int nblk = (n_b + SF_R - 1) / SF_R;
     // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups

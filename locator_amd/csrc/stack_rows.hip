@@ -209,9 +209,207 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
     }
 }
 
-// rows from which the MFMA form beats the row-parallel vector-ALU kernel (128 workgroups of 32 rows; below that too few
-// workgroups to fill the chip, and a workgroup's nine dependent layers take ~60 us whatever the row count)
-extern "C" int loc_stack_rows_min_rows(void) { return 3072; }
+// ---------------------------------------------------------------------------------------------------------
+// 16 rows per workgroup on v_mfma_f32_16x16x4_f32 (round 5).  At 3072..8191 rows per chunk the 32-row form has 96..255
+// workgroups for 256 compute units and every one of them walks its nine dependent layers for ~60 us whatever the row count
+// (117 us at 4096 rows where the MFMAs of a FULL chip would need 38).  Halving the row tile doubles the workgroups and halves
+// each one's MFMA time per layer (128 MFMAs of 32 cycles per wave and layer instead of 128 of 64); the weight stream per
+// workgroup is the same, i.e. twice the L2 -> CU traffic per row (2.3 MB per 16 rows: 0.6 GB at 4096 rows, far from a limit).
+//   wave w (of 8) owns units [32 w, 32 w + 32) as two 16-unit tiles t:  D[i = row][j = unit] += A[i][k] B[k][j], four k per MFMA:
+//   lane = (i16 = lane & 15, kq = lane >> 4), k = 64 kq + s for step s = 0..63, so that a lane's A values are CONSECUTIVE floats
+//   of its row (one ds_read_b128 per four steps = eight MFMAs) and its B values are W[64 kq + s][32 w + 16 t + i16], read back
+//   from the same per-wave LDS stage as the 32-row form: chunk c = steps 8 c .. 8 c + 7 of the four k quarters = 32 rows of W x
+//   32 units = four 16-byte requests per lane, three chunks ahead across layer boundaries.  Stage row ri = 8 kq + r at
+//   ri 32 + 16 (ri >> 3) floats: the four k quarters of a read fall on different bank halves.
+//   D register r of a lane is row 4 kq + r, unit 16 t + i16.
+#define SR16_ROWS 16
+__global__ __launch_bounds__(512) void stack_rows16_eval_kernel(
+    const float* __restrict__ a1, const float* __restrict__ rd_partial, int rd_G, int64_t rd_MH,
+    const float* __restrict__ rd_cvec8, const float* __restrict__ rd_b1, const float* __restrict__ Wh,
+    const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba, const float* __restrict__ wb,
+    const float* __restrict__ bb, int L, int n_b, const int32_t* __restrict__ rows, const float* __restrict__ Y,
+    float* __restrict__ yhat, float* __restrict__ dist) {
+    constexpr int Hp = SR_HP, P = SR_PITCH, R = SR16_ROWS;
+    extern __shared__ __attribute__((aligned(16))) float sr_smem[];
+    float (*act)[R * P] = reinterpret_cast<float (*)[R * P]>(sr_smem);
+    float (*hp)[R][2] = reinterpret_cast<float (*)[R][2]>(sr_smem + 2 * R * P);
+    float* wst = sr_smem + 2 * R * P + 8 * R * 2;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, i16 = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.x * R;
+    const int64_t HH = (int64_t)Hp * Hp;
+
+    constexpr int WS = 32 * 32 + 64;                     // floats per stage (32 rows of 32 + 16 floats of shift per k quarter)
+    float* stg = wst + w * 2 * WS;
+    const int grow = lane >> 3, gcol = 4 * (lane & 7);   // this lane's row (of 8 per request) and column quad
+    f32x4 g[4];
+    auto gload = [&](const float* __restrict__ W, int c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                      // request q = k quarter q, rows 8 c + grow of it
+            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(64 * q + 8 * c + grow) * Hp + 32 * w + gcol);
+    };
+    auto sput = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stg + buf * WS + (8 * q + grow) * 32 + 16 * q + gcol) = g[q];
+    };
+    auto bget = [&](int buf, float (&bv)[16]) {          // bv[2 e + t]: step e of the chunk, unit tile t
+        const float* p = stg + buf * WS + (8 * kq) * 32 + 16 * kq + i16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bv[2 * e] = p[e * 32];
+            bv[2 * e + 1] = p[e * 32 + 16];
+        }
+    };
+    float bA[16], bB[16];
+    gload(Wh, 0); sput(0);
+    gload(Wh, 1); sput(1);
+    gload(Wh, 2);
+
+    // ---- input: rows of this workgroup -> act[0]
+    if (rd_partial != nullptr) {
+        const int gq = (rd_G + 3) / 4;
+        for (int i = t; i < R * Hp; i += 512) {
+            const int r = i / Hp, n = i % Hp;
+            float v = 0.f;
+            if (r0 + r < n_b) {
+                const float* src = rd_partial + (int64_t)(r0 + r) * Hp + n;
+                float sq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g0 = q * gq, g1 = g0 + gq < rd_G ? g0 + gq : rd_G;
+                    float z = 0.f;
+                    for (int gg = g0; gg < g1; ++gg) z += src[(int64_t)gg * rd_MH];
+                    sq[q] = z;
+                }
+                float c = rd_cvec8[n];
+#pragma unroll
+                for (int sl = 1; sl < 8; ++sl) c += rd_cvec8[sl * Hp + n];
+                v = elu_f((((sq[0] + sq[1]) + sq[2]) + sq[3]) + (c + rd_b1[n]));
+            }
+            act[0][r * P + n] = v;
+        }
+    } else {
+        for (int i = t; i < R * Hp / 4; i += 512) {      // 16-byte loads: 64 per row
+            const int r = i / (Hp / 4), n4 = (i % (Hp / 4)) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + r < n_b) v = *reinterpret_cast<const f32x4*>(a1 + (int64_t)(r0 + r) * Hp + n4);
+            *reinterpret_cast<f32x4*>(&act[0][r * P + n4]) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- layers 2..L
+    int cur = 0;
+    bget(0, bA);
+    for (int l = 2; l <= L; ++l) {
+        const float* Wc = Wh + (int64_t)(l - 2) * HH;
+        const float* Wn = l < L ? Wc + HH : Wh;                // after the last layer: a dummy prefetch, never used
+        const float bias0 = bh[(int64_t)(l - 2) * Hp + 32 * w + i16], bias1 = bh[(int64_t)(l - 2) * Hp + 32 * w + 16 + i16];
+        const float* arow = act[cur] + i16 * P + 64 * kq;      // this lane's row, its quarter of the k range
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < 8; c += 2) {
+            {
+                bget(1, bB);
+                f32x4 a4[2];
+                a4[0] = *reinterpret_cast<const f32x4*>(arow + 8 * c);
+                a4[1] = *reinterpret_cast<const f32x4*>(arow + 8 * c + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e + 1], acc1, 0, 0, 0);
+                }
+                sput(0);                                       // chunk c + 2 (stage 0 was read into bA an iteration ago)
+                if (c + 3 < 8) gload(Wc, c + 3); else gload(Wn, c + 3 - 8);
+            }
+            {
+                bget(0, bA);                                   // chunk c + 2
+                f32x4 a4[2];
+                a4[0] = *reinterpret_cast<const f32x4*>(arow + 8 * (c + 1));
+                a4[1] = *reinterpret_cast<const f32x4*>(arow + 8 * (c + 1) + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e + 1], acc1, 0, 0, 0);
+                }
+                sput(1);                                       // chunk c + 3
+                if (c + 4 < 8) gload(Wc, c + 4); else gload(Wn, c + 4 - 8);
+            }
+        }
+        // bias + ELU -> the other activation buffer: register r of a lane is row 4 kq + r, unit 32 w + 16 t + i16
+        float* out = act[cur ^ 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out[(4 * kq + r) * P + 32 * w + i16] = elu_f(acc0[r] + bias0);
+            out[(4 * kq + r) * P + 32 * w + 16 + i16] = elu_f(acc1[r] + bias1);
+        }
+        cur ^= 1;
+        sr_lds_barrier();
+    }
+    asm volatile("" ::"v"(bA[0]), "v"(bB[0]), "v"(g[0]));
+
+    // ---- Dense(2), Dense(2), distance (locator.py:324-325, :314-315): per row, fixed summation order
+    {
+        const float* af = act[cur];
+        const int jl = lane & 31, hi = lane >> 5, u = 32 * w + jl;
+        const float w0 = wa[2 * u], w1 = wa[2 * u + 1];
+        // lane (unit u, half hi) covers rows 8 hi .. 8 hi + 7: sum over the 32 units of this wave by lane shuffles
+#pragma unroll 4
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = 8 * hi + rr;
+            const float a = af[row * P + u];
+            float p0 = a * w0, p1 = a * w1;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+            if (jl == 0) { hp[w][row][0] = p0; hp[w][row][1] = p1; }
+        }
+        sr_lds_barrier();
+        if (t < R) {
+            const int b = r0 + t;
+            if (b < n_b) {
+                float y10 = ba[0], y11 = ba[1];
+                for (int w2 = 0; w2 < 8; ++w2) { y10 += hp[w2][t][0]; y11 += hp[w2][t][1]; }
+                const float y20 = y10 * wb[0] + y11 * wb[2] + bb[0];
+                const float y21 = y10 * wb[1] + y11 * wb[3] + bb[1];
+                yhat[2 * (int64_t)b] = y20;
+                yhat[2 * (int64_t)b + 1] = y21;
+                if (dist != nullptr && Y != nullptr) {
+                    const int64_t yr = rows[b];
+                    const float e0 = y20 - Y[2 * yr], e1 = y21 - Y[2 * yr + 1];
+                    dist[b] = sqrtf(fmaxf(e0 * e0 + e1 * e1, 0.f));
+                }
+            }
+        }
+    }
+}
+
+
+// Rows from which the MFMA forms beat the row-parallel vector-ALU kernel: a workgroup's nine dependent layers take their time
+// whatever the row count - measured (tools/stack_rows_bench.py, profiles/r05_stack_rows_bench.jsonl) 60-64 us per round of
+// 16-row workgroups and 103-106 us per round of 32-row workgroups, a round = one workgroup per compute unit (the LDS holds
+// one), against 0.047 us per row on the vector ALU (53.8 us at 1024 rows, 78.8 at 1536).  Between the two MFMA forms the
+// one with the smaller rounds x time-per-round wins: 16-row tiles up to 4096 rows (64 against 103 us) and at 8193..12288
+// (179 against 210), 32-row tiles elsewhere (4097..8192: 106 against 120; 16,384: 214 against 239).
+#define SR_MIN_ROWS 1280
+#define SR16_ROUND_US 61
+#define SR32_ROUND_US 105
+static int sr_compute_units() {
+    static int ncu[LOC_MAX_DEVICES] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : dev % LOC_MAX_DEVICES;
+    if (ncu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        ncu[dev] = v;
+    }
+    return ncu[dev];
+}
+static bool sr_takes_16_row_tiles(int n_b) {
+    const int cu = sr_compute_units();
+    const int r16 = ((n_b + 15) / 16 + cu - 1) / cu, r32 = ((n_b + 31) / 32 + cu - 1) / cu;
+    return r16 * SR16_ROUND_US < r32 * SR32_ROUND_US;
+}
+extern "C" int loc_stack_rows_min_rows(void) { return SR_MIN_ROWS; }
 extern "C" int loc_stack_rows_supported(int Hp, int L) { return Hp == SR_HP && L >= 2; }
 
 #ifdef SR_STAMPS
@@ -223,9 +421,18 @@ extern "C" int loc_debug_sr_occupancy(int lds_bytes) {
 }
 #endif
 
+// tile_rows: 32 or 16 = that form; 0 = by row count
 int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t rd_MH, const float* rd_cvec8, const float* rd_b1,
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
-                   int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, void* stream) {
+                   int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, int tile_rows, void* stream) {
+    if (tile_rows == 16 || (tile_rows == 0 && sr_takes_16_row_tiles(n_b))) {
+        constexpr size_t lds16 = (2 * SR16_ROWS * SR_PITCH + 8 * SR16_ROWS * 2 + 8 * 2 * (32 * 32 + 64)) * sizeof(float);
+        LOC_ENSURE_LDS(stack_rows16_eval_kernel, lds16);
+        hipLaunchKernelGGL(stack_rows16_eval_kernel, dim3((n_b + SR16_ROWS - 1) / SR16_ROWS), dim3(512), lds16, (hipStream_t)stream,
+                           a1, rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist);
+        LOC_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr size_t lds = (2 * SR_ROWS * SR_PITCH + 8 * SR_ROWS * 2 + 8 * 2 * (32 * 32 + 32)) * sizeof(float);
     LOC_ENSURE_LDS(stack_rows_eval_kernel, lds);
     hipLaunchKernelGGL(stack_rows_eval_kernel, dim3((n_b + SR_ROWS - 1) / SR_ROWS), dim3(512), lds, (hipStream_t)stream, a1,

@@ -414,8 +414,7 @@ class LocatorNet:
             # per-call choices never outlive the call, whether it succeeded or raised (the struct is cached)
             net.predict_digits = self.predict_digits if self.predict_digits != 0 else 3
             net.predict_pieces = self.predict_pieces
-            net.l1_scan_ready = 0
-            net.l1_image_ready = 0
+            net.l1_scan_ready = 0                 # (l1_image_ready is set afresh by every call and records what the last one used)
 
     def quant_guard(self):
         """(median R, largest R, digit planes allowed, digit planes allowed in exact mode) of the current parameters, R_h =

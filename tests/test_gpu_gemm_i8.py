@@ -71,7 +71,8 @@ def decode_image(image, d, digits):
     raw = image.cpu().numpy()
     nkt = ((d.Kp + 63) // 64 + 1) & ~1
     delta = raw[8 * G8_HP * 4: 9 * G8_HP * 4].view(np.float32).copy()
-    tiles_off = (11 * G8_HP * 4 + nkt * G8_HP * 4 + 1023) // 1024 * 1024      # cvec8 | delta | colmax | guard | cpart | tiles
+    from locator_amd import _lib
+    tiles_off = int(_lib.load().loc_l1_image_i8_tiles_offset(C.byref(d)))    # cvec8 | delta | colmax | guard | scan shares | tiles
     t = raw[tiles_off: tiles_off + nkt * digits * G8_TILE].view(np.int8).reshape(nkt, digits, 4, G8_HP, 16)
     q = np.zeros((nkt, 4, G8_HP, 16), np.int64)
     for p in range(digits):
@@ -253,7 +254,8 @@ def test_second_predict_with_unchanged_weights_reuses_the_image_and_any_change_r
     y1, y2, y3 = (torch.zeros((n, 2), device="cuda") for _ in range(3))
     net.predict_rows(rows, n, y1)
     assert net._image_mode == 13 and net._net.l1_image_ready == 0
-    sl = slice(50_000, 54_096)                        # inside the first digit tiles (they start at byte 43,008)
+    t0 = int(net.lib.loc_l1_image_i8_tiles_offset(C.byref(net.d)))
+    sl = slice(t0 + 8192, t0 + 12288)                 # inside the first digit tiles
     assert net.l1_image[sl].any()
     net.l1_image[sl].zero_()                          # if the second call rebuilt the image these bytes would come back
     tail = net.l1_image[sl].clone()
