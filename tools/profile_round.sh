@@ -10,7 +10,7 @@
 #   gpurun_out/<tag>_gemm_pmc_1000.json, _4096.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters (with the effective
 #                                                 clock from GRBM_GUI_ACTIVE) and kernel times, int8 and bf16 kernels
 # Copy what should be judged into profiles/ (tracked).
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -37,6 +37,12 @@ rm -rf $O/gemm_kt
 rocprofv3 --kernel-trace --stats -d $O/gemm_kt -o k --output-format csv -- python3 $R/tools/rows_gemm_bench.py --rows 1000,4096 --iters 20 > $O/${TAG}_gemm_bench.log 2>&1
 cp $O/gemm_kt/k_kernel_stats.csv $O/${TAG}_gemm_kernel_stats.csv
 python3 $R/tools/rows_gemm_bench.py --rows 4096,16384 --iters 10 --i8-only --packed >> $O/${TAG}_gemm_bench.log 2>&1    # 2-bit packed genotypes
+# round 5 evidence: the full predict-mode x shape GEMM sweep (out of the bench line since round 5), the hidden-stack forms over
+# row counts, the split-K hand-over probe, the README windows example in every replicate layout
+python3 $R/tools/l1_gemm_sweep.py --out $O/${TAG}_l1_gemm_sweep.json > $O/l1_gemm_sweep.log 2>&1
+python3 $R/tools/stack_rows_bench.py 2>/dev/null | grep rows > $O/${TAG}_stack_rows_bench.jsonl
+( cd $R/tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 splitk_reduce_probe.hip -o splitk_reduce_probe 2>/dev/null; ./splitk_reduce_probe > $O/${TAG}_splitk_probe.jsonl 2>&1 )
+( cd $R && python3 tools/readme_windows.py --busy --repeat 2 > $O/${TAG}_readme_windows.json 2> $O/readme_windows.err )
 # round 4 evidence: trained-weight tolerance of the predict modes, quantisation study, fit timelines, predict timeline
 cd $R
 python3 -m pytest tests/test_gpu_trained_predict.py -q -s > $O/${TAG}_trained_predict.log 2>&1
