@@ -369,6 +369,9 @@ def _device_matrix(model, traingen, testgen, trainlocs, testlocs):
     return X, torch.from_numpy(yh).to(model.device), tr0, va0
 
 
+GRAPH_MAX_SNPS_IN_FIT_THREADS = 65536      # fit threads sharing a process capture epoch graphs up to this many SNPs (train_network)
+
+
 def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot=0):
     """model.fit with the three callbacks, then the best-val_loss weights back in the model (locator.py:365-394)."""
     from .train import History, fit
@@ -389,9 +392,14 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
                              "genotypes and filters (--min_mac, --max_SNPs, --impute_missing), --width and --nlayers")
         history = History()
     else:
-        # (round 5: fit threads that share a process capture their epoch graphs too - train.DEVICE_LOCK keeps a capture
-        # apart from a sibling's set-up / read-back / tear-down; round 4 launched them eagerly)
-        use_graph = not args.no_graph
+        # Round 5: fit threads that share a process capture their epoch graphs too - train.DEVICE_LOCK keeps a capture apart
+        # from a sibling's set-up / read-back / tear-down (round 4 launched them eagerly) - where replay pays: with two fits
+        # interleaving on one GPU an eagerly launched epoch costs host time, and that is hidden behind the device once a step's
+        # kernels are long.  Measured (profiles/r05_readme_windows.json, r05_config4_workers.txt): 1,150 SNPs per window
+        # 0.23 s per fit with graphs against 0.26-0.44 s eager; 150,000 SNPs 1.19 s against 1.17 s (two captures per fit cost
+        # more than replay saves).  A fit alone in its process always replays (bench.py, single runs).
+        from . import replicates
+        use_graph = not args.no_graph and (replicates.fit_threads_in_process() <= 1 or model.net.d.K <= GRAPH_MAX_SNPS_IN_FIT_THREADS)
         history = fit(model.net, np.arange(tr0, tr0 + ntr), np.arange(va0, va0 + nva), batch_size=args.batch_size,
                       max_epochs=args.max_epochs, patience=earlystop["patience"], lr_patience=reducelr["patience"],
                       lr_factor=reducelr["factor"], use_graph=use_graph, verbose=args.keras_verbose,
@@ -723,7 +731,7 @@ def _print_replicate_summary(pool, results, t_program):
         mean = lambda k: sum(r["phases"].get(k, 0.0) for r in ok) / len(ok)
         host = sum(r.get("host_prepare_seconds", 0.0) for r in ok) / len(ok)
         print(f"replicate phases, mean of {len(ok)} units: host slice+filter {host:.2f} s (loader thread), load-in-fit "
-              f"{mean('load'):.2f} s, upload {mean('upload'):.2f} s, fit {mean('fit'):.2f} s, predict {mean('predict'):.2f} s")
+              f"{mean('load'):.2f} s, upload {mean('upload'):.2f} s, fit {mean('fit'):.3f} s, predict {mean('predict'):.3f} s")
     for line in pool.summary(results, program_started=t_program)["lines"]:
         print(line)
 
