@@ -101,7 +101,7 @@ typedef struct loc_tuning {
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
     int stack_rows;       /* hidden stack of a many-row predict: 0 = default: from loc_stack_rows_min_rows() (1280) rows per chunk
-                             the fp32 matrix pipe - 16 or 32 rows per workgroup, whichever needs less rounds x time per round
+                             the fp32 matrix pipe - 16 or 32 rows per workgroup, whichever the measured time model puts ahead
                              on this device's compute units (16-row tiles up to 4096 rows and at 8193..12288 on 256 units) -
                              and 2 rows per workgroup on the vector ALU below; 1 = the 32-row matrix-pipe form for every
                              chunk; 2 = the 16-row form for every chunk; -1 = never (measurement switch)                    */

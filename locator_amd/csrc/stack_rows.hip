@@ -222,8 +222,13 @@ __global__ __launch_bounds__(512) void stack_rows_eval_kernel(
 //   32 units = four 16-byte requests per lane, three chunks ahead across layer boundaries.  Stage row ri = 8 kq + r at
 //   ri 32 + 16 (ri >> 3) floats: the four k quarters of a read fall on different bank halves.
 //   D register r of a lane is row 4 kq + r, unit 16 t + i16.
+//   CS = steps per weight chunk: 4 is what ships (71 KB of LDS: TWO workgroups per compute unit, so that one's epilogue, barrier
+//   and stage traffic sit under the other's MFMAs once there are more workgroups than compute units); 8 (104 KB, one
+//   workgroup per compute unit) was the first form and measured 3-15 % slower at every row count
+//   (profiles/r05_stack_rows_bench_2percu.jsonl: 4096 rows 66.5 against 63.6 us, 12,288 rows 186 against 165).
 #define SR16_ROWS 16
-__global__ __launch_bounds__(512) void stack_rows16_eval_kernel(
+template <int CS>
+__global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel(
     const float* __restrict__ a1, const float* __restrict__ rd_partial, int rd_G, int64_t rd_MH,
     const float* __restrict__ rd_cvec8, const float* __restrict__ rd_b1, const float* __restrict__ Wh,
     const float* __restrict__ bh, const float* __restrict__ wa, const float* __restrict__ ba, const float* __restrict__ wb,
@@ -238,28 +243,36 @@ __global__ __launch_bounds__(512) void stack_rows16_eval_kernel(
     const int r0 = blockIdx.x * R;
     const int64_t HH = (int64_t)Hp * Hp;
 
-    constexpr int WS = 32 * 32 + 64;                     // floats per stage (32 rows of 32 + 16 floats of shift per k quarter)
+    static_assert(CS == 8 || CS == 4, "steps per chunk");
+    constexpr int NQ = CS / 2;                           // 16-byte requests per lane and chunk (4 CS rows of W x 128 bytes per wave)
+    constexpr int NCH = 64 / CS;                         // chunks per layer
+    constexpr int WS = 4 * CS * 32 + 64;                 // floats per stage (4 CS rows of 32 + 16 floats of shift per k quarter)
     float* stg = wst + w * 2 * WS;
     const int grow = lane >> 3, gcol = 4 * (lane & 7);   // this lane's row (of 8 per request) and column quad
-    f32x4 g[4];
+    f32x4 g[NQ];
     auto gload = [&](const float* __restrict__ W, int c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)                      // request q = k quarter q, rows 8 c + grow of it
-            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(64 * q + 8 * c + grow) * Hp + 32 * w + gcol);
+        for (int q = 0; q < NQ; ++q) {                   // stage row ri = 8 q + grow = CS x (k quarter) + (step in the chunk)
+            const int ri = 8 * q + grow;
+            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(64 * (ri / CS) + CS * c + ri % CS) * Hp + 32 * w + gcol);
+        }
     };
     auto sput = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(stg + buf * WS + (8 * q + grow) * 32 + 16 * q + gcol) = g[q];
+        for (int q = 0; q < NQ; ++q) {
+            const int ri = 8 * q + grow;
+            *reinterpret_cast<f32x4*>(stg + buf * WS + ri * 32 + 16 * (ri / CS) + gcol) = g[q];
+        }
     };
-    auto bget = [&](int buf, float (&bv)[16]) {          // bv[2 e + t]: step e of the chunk, unit tile t
-        const float* p = stg + buf * WS + (8 * kq) * 32 + 16 * kq + i16;
+    auto bget = [&](int buf, float (&bv)[2 * CS]) {      // bv[2 e + t]: step e of the chunk, unit tile t
+        const float* p = stg + buf * WS + (CS * kq) * 32 + 16 * kq + i16;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < CS; ++e) {
             bv[2 * e] = p[e * 32];
             bv[2 * e + 1] = p[e * 32 + 16];
         }
     };
-    float bA[16], bB[16];
+    float bA[2 * CS], bB[2 * CS];
     gload(Wh, 0); sput(0);
     gload(Wh, 1); sput(1);
     gload(Wh, 2);
@@ -307,32 +320,32 @@ __global__ __launch_bounds__(512) void stack_rows16_eval_kernel(
         const float* arow = act[cur] + i16 * P + 64 * kq;      // this lane's row, its quarter of the k range
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int c = 0; c < 8; c += 2) {
+        for (int c = 0; c < NCH; c += 2) {
             {
                 bget(1, bB);
-                f32x4 a4[2];
-                a4[0] = *reinterpret_cast<const f32x4*>(arow + 8 * c);
-                a4[1] = *reinterpret_cast<const f32x4*>(arow + 8 * c + 4);
+                f32x4 a4[CS / 4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int q = 0; q < CS / 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + CS * c + 4 * q);
+#pragma unroll
+                for (int e = 0; e < CS; ++e) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e + 1], acc1, 0, 0, 0);
                 }
                 sput(0);                                       // chunk c + 2 (stage 0 was read into bA an iteration ago)
-                if (c + 3 < 8) gload(Wc, c + 3); else gload(Wn, c + 3 - 8);
+                if (c + 3 < NCH) gload(Wc, c + 3); else gload(Wn, c + 3 - NCH);
             }
             {
                 bget(0, bA);                                   // chunk c + 2
-                f32x4 a4[2];
-                a4[0] = *reinterpret_cast<const f32x4*>(arow + 8 * (c + 1));
-                a4[1] = *reinterpret_cast<const f32x4*>(arow + 8 * (c + 1) + 4);
+                f32x4 a4[CS / 4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int q = 0; q < CS / 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + CS * (c + 1) + 4 * q);
+#pragma unroll
+                for (int e = 0; e < CS; ++e) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e + 1], acc1, 0, 0, 0);
                 }
                 sput(1);                                       // chunk c + 3
-                if (c + 4 < 8) gload(Wc, c + 4); else gload(Wn, c + 4 - 8);
+                if (c + 4 < NCH) gload(Wc, c + 4); else gload(Wn, c + 4 - NCH);
             }
         }
         // bias + ELU -> the other activation buffer: register r of a lane is row 4 kq + r, unit 32 w + 16 t + i16
@@ -384,13 +397,16 @@ __global__ __launch_bounds__(512) void stack_rows16_eval_kernel(
 
 
 // Rows from which the MFMA forms beat the row-parallel vector-ALU kernel: a workgroup's nine dependent layers take their time
-// whatever the row count - measured (tools/stack_rows_bench.py, profiles/r05_stack_rows_bench.jsonl) 60-64 us per round of
-// 16-row workgroups and 103-106 us per round of 32-row workgroups, a round = one workgroup per compute unit (the LDS holds
-// one), against 0.047 us per row on the vector ALU (53.8 us at 1024 rows, 78.8 at 1536).  Between the two MFMA forms the
-// one with the smaller rounds x time-per-round wins: 16-row tiles up to 4096 rows (64 against 103 us) and at 8193..12288
-// (179 against 210), 32-row tiles elsewhere (4097..8192: 106 against 120; 16,384: 214 against 239).
+// whatever the row count.  Measured on 256 compute units (tools/stack_rows_bench.py, profiles/r05_stack_rows_bench*.jsonl):
+//   vector ALU, 2 rows per workgroup    0.047 us per row (53.8 us at 1024 rows, 78.8 at 1536)
+//   32-row tiles, one per compute unit   103-106 us per round of workgroups (8192 rows)
+//   16-row tiles, two per compute unit   64 us up to one workgroup per compute unit (4096 rows), then + 50-55 us per further
+//                                        4096 rows (110 us at 8192, 165 at 12,288, 216 at 16,384)
+// The launcher takes the matrix-pipe form with the smaller modelled time: 16-row tiles up to 4096 rows and at 8193..12,288,
+// 32-row tiles at 4097..8192 and 12,289..16,384 (a predict chunk is at most 16,384 rows).
 #define SR_MIN_ROWS 1280
-#define SR16_ROUND_US 61
+#define SR16_FIRST_US 12
+#define SR16_ROUND_US 52
 #define SR32_ROUND_US 105
 static int sr_compute_units() {
     static int ncu[LOC_MAX_DEVICES] = {};
@@ -407,7 +423,7 @@ static int sr_compute_units() {
 static bool sr_takes_16_row_tiles(int n_b) {
     const int cu = sr_compute_units();
     const int r16 = ((n_b + 15) / 16 + cu - 1) / cu, r32 = ((n_b + 31) / 32 + cu - 1) / cu;
-    return r16 * SR16_ROUND_US < r32 * SR32_ROUND_US;
+    return SR16_FIRST_US + r16 * SR16_ROUND_US < r32 * SR32_ROUND_US;
 }
 extern "C" int loc_stack_rows_min_rows(void) { return SR_MIN_ROWS; }
 extern "C" int loc_stack_rows_supported(int Hp, int L) { return Hp == SR_HP && L >= 2; }
@@ -426,9 +442,10 @@ int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t r
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
                    int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, int tile_rows, void* stream) {
     if (tile_rows == 16 || (tile_rows == 0 && sr_takes_16_row_tiles(n_b))) {
-        constexpr size_t lds16 = (2 * SR16_ROWS * SR_PITCH + 8 * SR16_ROWS * 2 + 8 * 2 * (32 * 32 + 64)) * sizeof(float);
-        LOC_ENSURE_LDS(stack_rows16_eval_kernel, lds16);
-        hipLaunchKernelGGL(stack_rows16_eval_kernel, dim3((n_b + SR16_ROWS - 1) / SR16_ROWS), dim3(512), lds16, (hipStream_t)stream,
+        // 16-row tiles, four-step weight chunks: 71 KB of LDS, two workgroups per compute unit
+        constexpr size_t lds16 = (2 * SR16_ROWS * SR_PITCH + 8 * SR16_ROWS * 2 + 8 * 2 * (4 * 4 * 32 + 64)) * sizeof(float);
+        LOC_ENSURE_LDS(stack_rows16_eval_kernel<4>, lds16);
+        hipLaunchKernelGGL(stack_rows16_eval_kernel<4>, dim3((n_b + SR16_ROWS - 1) / SR16_ROWS), dim3(512), lds16, (hipStream_t)stream,
                            a1, rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist);
         LOC_CHECK_LAUNCH();
         return 0;
