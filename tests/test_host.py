@@ -400,6 +400,45 @@ def test_window_loader_falls_back_to_the_host_path_for_a_store_that_is_not_int8(
         assert got["i16"][k].dtype == got["i8"][k].dtype and np.array_equal(got["i8"][k], got["i16"][k]), k
 
 
+def test_device_lock_is_reentrant_per_thread_and_released_drops_the_whole_hold():
+    """train.DEVICE_LOCK (round 5): what keeps a HIP-graph capture apart from a sibling fit thread's set-up / read-back /
+    tear-down.  Re-entrant for the thread that holds it; `released()` lets go of every nested hold for the duration of a
+    block (FitLoop.run's epoch loop) and takes them back; another thread gets in exactly while it is released."""
+    import threading
+    import time
+    from locator_amd.train import _DeviceLock
+    lock = _DeviceLock()
+    order = []
+
+    def sibling():
+        with lock:
+            order.append("sibling in")
+            time.sleep(0.05)
+            order.append("sibling out")
+
+    with lock:
+        with lock:                                  # nested hold (locator._fit_unit -> FitLoop.finish)
+            assert lock.held()
+            t = threading.Thread(target=sibling)
+            t.start()
+            time.sleep(0.1)
+            assert order == []                      # the sibling waits while this thread holds the lock
+            with lock.released():
+                assert not lock.held()
+                t.join(2)
+                assert order == ["sibling in", "sibling out"]
+            assert lock.held()                      # ... and both holds are back
+        assert lock.held()
+    assert not lock.held()
+    with lock.released():                           # a no-op for a thread that holds nothing
+        assert not lock.held()
+    got = []
+    t = threading.Thread(target=lambda: (lock.__enter__(), got.append(1), lock.__exit__(None, None, None)))
+    t.start()
+    t.join(2)
+    assert got == [1]
+
+
 def test_bench_launches_its_own_ranks_without_torchrun(repo_root):
     """`python bench.py --gpus N` with no launcher: the parent starts N rank processes before touching a GPU, the
     ranks rendezvous on 127.0.0.1, barrier, take the max over ranks, and rank 0's single JSON line comes back through
