@@ -571,7 +571,11 @@ def _pin_take(nbytes):
             if t.numel() >= nbytes:
                 return _PIN_POOL.pop(i)
         _PIN_POOL.clear()                               # too small for this window: let them go, allocate with head room
-    return torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8).pin_memory()
+    # (a pinned allocation is a runtime call the loader thread makes while fit threads may be capturing graphs: it waits for
+    # an open capture like every other out-of-loop device call, train.DEVICE_LOCK)
+    from .train import DEVICE_LOCK
+    with DEVICE_LOCK:
+        return torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8).pin_memory()
 
 
 def _pin_give(t):
