@@ -217,7 +217,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
                            "takes": ("int8x%d" % int(g[2]) if g[2] > 0 else "bf16x3") + ", from the 2-bit packed matrix for chunks of "
                                     ">= 3072 rows (packed automatically when the genotypes are <= 3); the hidden stack that follows takes the "
                                     "fp32 matrix pipe from 3072 rows per chunk (us_stack)"}
-    res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_colmax_kernel "
+    res["kernel"] = ("int8: l1_gemm_i8_kernel + l1_gemm_reduce_kernel (digit planes written once per predict by l1_scan_kernel "
                      "+ l1_image_i8_kernel); bf16: l1_gemm_kernel + l1_gemm_reduce_kernel (l1_image_kernel)")
     res["jacknife_shape_4096_rows"] = shape(net.X, 4096, n_matrix, in_loop=False)
     res["jacknife_shape_16384_rows"] = shape(net.X, 16384, n_matrix, in_loop=False)     # one LOC_PREDICT_CHUNK

@@ -1,4 +1,4 @@
-"""Kernel times of the dynamic-range scan (l1_colmax_kernel + l1_quant_guard_kernel) in isolation: run under
+"""Kernel times of the dynamic-range scan (l1_scan_kernel + l1_quant_guard_kernel; round 4: l1_colmax_kernel) in isolation: run under
     rocprofv3 --kernel-trace --stats -- python3 tools/probes/guard_time.py"""
 import ctypes as C
 import os
