@@ -110,7 +110,7 @@ __host__ __device__ inline int64_t w1s_index(int h, int k, int nht) {
 // host-side error plumbing (api.hip)
 void loc_set_error(const char* fmt, ...);
 // l1_gemm.hip: the shift-term and SNP-group reductions shared by the bf16 and int8 large-M GEMMs
-int gm_launch_cvec(const float* cpart, int nkt64, float* cvec8, void* stream);   // (bf16 image only since round 5)
+int gm_launch_cvec(const float* cpart, int nkt64, float* cvec8, void* stream);
 int gm_launch_reduce(const float* partial, int G, int64_t MH, const float* cvec8, const float* b1, float* a1,
                      void* stream);
 
