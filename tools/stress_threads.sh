@@ -1,7 +1,7 @@
 cd /root/repo
 fail=0
 for i in $(seq 1 12); do
-  python -m pytest tests/test_gpu_parity.py -x -q -k "two_fit_threads" 2>&1 | tail -1
+  python tests/thread_capture_stress.py 2>&1 | tail -1
 done
 for i in 1 2 3; do
   python -m pytest tests/test_gpu_cli.py -x -q -k "bootstrap_outputs or windows_on_zarr" 2>&1 | tail -1
