@@ -861,6 +861,45 @@ def _quick_fit(unit, device="cpu"):
             "thread": threading.get_ident()}
 
 
+def test_eight_gpu_layout_on_cpu_one_worker_per_gpu_two_fit_threads_each(monkeypatch):
+    """The default 8-GPU layout (BASELINE configs[3] / [4]: replicates sharded over the GPUs of one node, no collective) with
+    the device count faked - no 8-GPU node was available to any round, so this is what can be shown here: 8 worker processes
+    (one per GPU index) x 2 fit threads = 16 concurrent fits; every unit fitted exactly once, records in unit order, every
+    GPU index used, no more workers than needed for few units, and the timeline's Amdahl projection is there.  A unit that
+    raises does not cost its worker; a worker that dies once does not cost its units."""
+    import time
+    monkeypatch.setattr(R, "visible_gpus", lambda: 8)
+    units = [dict(name=f"g{i}", replicate=i) for i in range(40)]
+    units[7]["explode"] = True
+    logs = []
+    pool = R.ReplicatePool(_Args(), _quick_fit, fits_per_gpu=2, procs_per_gpu=1, log=logs.append, poll_s=0.05,
+                           max_workers=len(units))
+    assert (pool.n_g, pool.n, pool.threads, pool.fits) == (8, 8, 2, 16)
+    t0 = time.time()
+    pool.start()
+    res = pool.run(units)
+    wall = time.time() - t0
+    pool.close()
+    assert [r["unit_index"] for r in res] == list(range(40))
+    assert "error" in res[7] and "boom" in res[7]["error"]
+    ok = [r for i, r in enumerate(res) if i != 7]
+    assert all("error" not in r and r["value"] == 2 * r["unit_index"] for r in ok)
+    assert {r["gpu"] for r in res} == set(range(8))
+    assert len({r["pid"] for r in ok}) == 8 and os.getpid() not in {r["pid"] for r in ok}
+    by_pid = {}
+    for r in ok:
+        by_pid.setdefault(r["pid"], set()).add(r["thread"])
+    assert all(len(t) == 2 for t in by_pid.values())                  # both fit threads of every worker worked
+    # 40 units of 0.4 s on 16 concurrent fits: 3 rounds = 1.2 s + worker start-up, far from the 16 s of one fit at a time
+    assert wall < 12, wall
+    s = pool.summary(res)
+    assert s["gpus"] == 8 and s["workers"] == 8 and s["fit_threads"] == 2 and s["units"] == 40
+    assert set(s["amdahl_projection_seconds"]) == {1, 2, 4, 8}
+    # few units: never more concurrent fits (and workers) than units
+    small = R.ReplicatePool(_Args(), _quick_fit, fits_per_gpu=2, procs_per_gpu=1, max_workers=3)
+    assert small.n * small.threads >= 3 and small.n <= 3
+
+
 def test_fit_threads_in_one_process_and_in_worker_processes():
     """VERDICT r03 next #4c: the concurrent fits of a GPU run as threads of ONE process (each on its own stream on a GPU;
     here the scheduling only).  One process x 2 threads (this process drives them) and 2 processes x 2 threads: every unit
