@@ -1,6 +1,7 @@
 #!/bin/bash
-# PMC passes on the many-row hidden-stack kernel (stack_rows.hip) at 16,384 rows (512 workgroups x 8 waves), on the GPU box:
-#   bash tools/stack_rows_pmc.sh   ->  gpurun_out/stack_rows_pmc.json
+# PMC passes on the many-row hidden-stack kernels (stack_rows.hip), on the GPU box:
+#   bash tools/stack_rows_pmc.sh                      32-row form at 16,384 rows (512 workgroups x 8 waves) -> gpurun_out/stack_rows_pmc.json
+#   ROWS=4096 TILE=16 bash tools/stack_rows_pmc.sh    16-row form (round 5) at 4096 rows (256 workgroups)
 # Separate rocprofv3 runs per counter set, --kernel-trace only beside --pmc; every run under `timeout`.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -13,20 +14,22 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MI
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE -d $O/sp3 -o p --output-format csv -- $B > $O/sp3.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
+TILE = int("${TILE:-32}")
+KPAT = "stack_rows16_eval" if TILE == 16 else "stack_rows_eval"
 acc = collections.defaultdict(list)
 dur = []
 for d in ("sp1", "sp2", "sp3"):
     for f in glob.glob("$O/" + d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "stack_rows_eval" in r["Kernel_Name"]:
+            if KPAT in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("$O/sp3/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "stack_rows_eval" in r["Kernel_Name"]:
+        if KPAT in r["Kernel_Name"]:
             dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 m = {c: sum(x) / len(x) for c, x in acc.items()}
 rows = int("${ROWS:-16384}")
-waves = 8.0 * ((rows + 31) // 32)
+waves = 8.0 * ((rows + TILE - 1) // TILE)
 out = {"source": "tools/stack_rows_pmc.sh (tools/predict_timeline.py --mode auto --rows %d; 100,000 SNPs)" % rows, "counters": m}
 if "SQ_WAVE_CYCLES" in m:
     cyc = 4 * m["SQ_WAVE_CYCLES"] / waves
