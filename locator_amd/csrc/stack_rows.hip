@@ -22,6 +22,7 @@
 // Optional input stage as in stack_fused.hip: the many-row GEMM's SNP-group partial sums are added up here (+ shift + b1,
 // ELU), same association as l1_gemm_reduce_kernel.
 #include "common.h"
+#include <type_traits>
 
 #define SR_HP 256
 #define SR_ROWS 32
@@ -249,19 +250,27 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
     constexpr int WS = 4 * CS * 32 + 64;                 // floats per stage (4 CS rows of 32 + 16 floats of shift per k quarter)
     float* stg = wst + w * 2 * WS;
     const int grow = lane >> 3, gcol = 4 * (lane & 7);   // this lane's row (of 8 per request) and column quad
-    f32x4 g[NQ];
-    auto gload = [&](const float* __restrict__ W, int c) {
+    // Register ring of RD chunks between the request and the stage write: a chunk is requested RD sub-iterations (of CS steps =
+    // 2 CS MFMAs of 32 cycles) before it is parked in the stage, i.e. RD + 2 chunks before its MFMAs.  The first 16-row form
+    // kept ONE chunk in registers (the 32-row form's schedule, where a sub-iteration is 1,024 cycles), which with four-step
+    // chunks leaves 256 cycles for an L2 round trip.  Measured: RD = 4 against 1 changes nothing at <= 4096 rows (65.6 against
+    // 65.3 us: the waves' parked half - profiles/r05_stack_rows16_pmc_4096.json, 0.53 - is not the weight stream) and gives
+    // 107 against 111 us at 8192 rows, two workgroups per compute unit; kept.
+    constexpr int RD = 4;
+    static_assert(NCH % RD == 0 && RD % 2 == 0, "the loop body is RD sub-iterations; stage parity = sub-iteration parity");
+    f32x4 g[RD][NQ];
+    auto gload = [&](const float* __restrict__ W, int c, f32x4 (&gv)[NQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {                   // stage row ri = 8 q + grow = CS x (k quarter) + (step in the chunk)
             const int ri = 8 * q + grow;
-            g[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(64 * (ri / CS) + CS * c + ri % CS) * Hp + 32 * w + gcol);
+            gv[q] = *reinterpret_cast<const f32x4*>(W + (int64_t)(64 * (ri / CS) + CS * c + ri % CS) * Hp + 32 * w + gcol);
         }
     };
-    auto sput = [&](int buf) {
+    auto sput = [&](int buf, const f32x4 (&gv)[NQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int ri = 8 * q + grow;
-            *reinterpret_cast<f32x4*>(stg + buf * WS + ri * 32 + 16 * (ri / CS) + gcol) = g[q];
+            *reinterpret_cast<f32x4*>(stg + buf * WS + ri * 32 + 16 * (ri / CS) + gcol) = gv[q];
         }
     };
     auto bget = [&](int buf, float (&bv)[2 * CS]) {      // bv[2 e + t]: step e of the chunk, unit tile t
@@ -273,9 +282,11 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
         }
     };
     float bA[2 * CS], bB[2 * CS];
-    gload(Wh, 0); sput(0);
-    gload(Wh, 1); sput(1);
-    gload(Wh, 2);
+    // chunks 0 and 1 of the first layer into the stages, chunks 2 .. RD + 1 into the ring (slot j holds chunk j + 2)
+    gload(Wh, 0, g[0]); gload(Wh, 1, g[1]);
+    sput(0, g[0]); sput(1, g[1]);
+#pragma unroll
+    for (int j = 0; j < RD; ++j) gload(Wh, j + 2, g[j]);
 
     // ---- input: rows of this workgroup -> act[0]
     if (rd_partial != nullptr) {
@@ -319,34 +330,33 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
         const float bias0 = bh[(int64_t)(l - 2) * Hp + 32 * w + i16], bias1 = bh[(int64_t)(l - 2) * Hp + 32 * w + 16 + i16];
         const float* arow = act[cur] + i16 * P + 64 * kq;      // this lane's row, its quarter of the k range
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // sub-iteration j of a loop trip handles chunk c + j: its B values are in bA (j even) / bB (j odd); it fetches chunk
+        // c + j + 1 from the other stage, issues its 2 CS MFMAs, parks ring slot j (chunk c + j + 2, requested RD sub-iterations
+        // ago) in its own stage and requests chunk c + j + 2 + RD into the slot.  Past the last chunk of a layer the stream
+        // continues with the next layer's first chunks (they do not depend on the activations).
+        auto sub = [&](int c, auto JC) {
+            constexpr int j = decltype(JC)::value, par = j & 1;
+            float (&bcur)[2 * CS] = par ? bB : bA;
+            float (&bnxt)[2 * CS] = par ? bA : bB;
+            bget(1 - par, bnxt);
+            f32x4 a4[CS / 4];
+#pragma unroll
+            for (int q = 0; q < CS / 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + CS * (c + j) + 4 * q);
+#pragma unroll
+            for (int e = 0; e < CS; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bcur[2 * e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bcur[2 * e + 1], acc1, 0, 0, 0);
+            }
+            sput(par, g[j]);
+            const int tc = c + j + 2 + RD;
+            if (tc < NCH) gload(Wc, tc, g[j]); else gload(Wn, tc - NCH, g[j]);
+        };
 #pragma unroll 1
-        for (int c = 0; c < NCH; c += 2) {
-            {
-                bget(1, bB);
-                f32x4 a4[CS / 4];
-#pragma unroll
-                for (int q = 0; q < CS / 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + CS * c + 4 * q);
-#pragma unroll
-                for (int e = 0; e < CS; ++e) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bA[2 * e + 1], acc1, 0, 0, 0);
-                }
-                sput(0);                                       // chunk c + 2 (stage 0 was read into bA an iteration ago)
-                if (c + 3 < NCH) gload(Wc, c + 3); else gload(Wn, c + 3 - NCH);
-            }
-            {
-                bget(0, bA);                                   // chunk c + 2
-                f32x4 a4[CS / 4];
-#pragma unroll
-                for (int q = 0; q < CS / 4; ++q) a4[q] = *reinterpret_cast<const f32x4*>(arow + CS * (c + 1) + 4 * q);
-#pragma unroll
-                for (int e = 0; e < CS; ++e) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e >> 2][e & 3], bB[2 * e + 1], acc1, 0, 0, 0);
-                }
-                sput(1);                                       // chunk c + 3
-                if (c + 4 < NCH) gload(Wc, c + 4); else gload(Wn, c + 4 - NCH);
-            }
+        for (int c = 0; c < NCH; c += RD) {
+            sub(c, std::integral_constant<int, 0>{});
+            sub(c, std::integral_constant<int, 1>{});
+            sub(c, std::integral_constant<int, 2>{});
+            sub(c, std::integral_constant<int, 3>{});
         }
         // bias + ELU -> the other activation buffer: register r of a lane is row 4 kq + r, unit 32 w + 16 t + i16
         float* out = act[cur ^ 1];
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
         cur ^= 1;
         sr_lds_barrier();
     }
-    asm volatile("" ::"v"(bA[0]), "v"(bB[0]), "v"(g[0]));
+    asm volatile("" ::"v"(bA[0]), "v"(bB[0]), "v"(g[0][0]), "v"(g[1][0]), "v"(g[2][0]), "v"(g[3][0]));
 
     // ---- Dense(2), Dense(2), distance (locator.py:324-325, :314-315): per row, fixed summation order
     {
