@@ -329,11 +329,15 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
         const float* Wn = l < L ? Wc + HH : Wh;                // after the last layer: a dummy prefetch, never used
         const float bias0 = bh[(int64_t)(l - 2) * Hp + 32 * w + i16], bias1 = bh[(int64_t)(l - 2) * Hp + 32 * w + 16 + i16];
         const float* arow = act[cur] + i16 * P + 64 * kq;      // this lane's row, its quarter of the k range
+        SR_STAMP(4 * (l - 2) + 0)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         // sub-iteration j of a loop trip handles chunk c + j: its B values are in bA (j even) / bB (j odd); it fetches chunk
         // c + j + 1 from the other stage, issues its 2 CS MFMAs, parks ring slot j (chunk c + j + 2, requested RD sub-iterations
         // ago) in its own stage and requests chunk c + j + 2 + RD into the slot.  Past the last chunk of a layer the stream
         // continues with the next layer's first chunks (they do not depend on the activations).
+        // (stamps, `make sr_stamps` + tools/probes/sr_stamps.py at 4096 rows: MFMA loop 9.6-13.3k cycles per layer and wave where
+        // the pipe needs 8.2k per SIMD, epilogue 1.4-2.6k, barrier wait 0.1-2.8k; reading the A values one sub-iteration ahead
+        // as well changed none of it and was taken out again)
         auto sub = [&](int c, auto JC) {
             constexpr int j = decltype(JC)::value, par = j & 1;
             float (&bcur)[2 * CS] = par ? bB : bA;
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
             sub(c, std::integral_constant<int, 2>{});
             sub(c, std::integral_constant<int, 3>{});
         }
+        SR_STAMP(4 * (l - 2) + 1)
         // bias + ELU -> the other activation buffer: register r of a lane is row 4 kq + r, unit 32 w + 16 t + i16
         float* out = act[cur ^ 1];
 #pragma unroll
@@ -366,7 +371,9 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
             out[(4 * kq + r) * P + 32 * w + 16 + i16] = elu_f(acc1[r] + bias1);
         }
         cur ^= 1;
+        SR_STAMP(4 * (l - 2) + 2)
         sr_lds_barrier();
+        SR_STAMP(4 * (l - 2) + 3)
     }
     asm volatile("" ::"v"(bA[0]), "v"(bB[0]), "v"(g[0][0]), "v"(g[1][0]), "v"(g[2][0]), "v"(g[3][0]));
 
