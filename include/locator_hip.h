@@ -100,11 +100,13 @@ typedef struct loc_tuning {
     int gemm_i8_unit_tiles; /* int8 GEMM: 32-unit tiles per wave: 1 = eight waves per workgroup (two per SIMD, 12 digit
                              fragments in flight each), 2 = four waves (one per SIMD, 512 registers, 32 in flight);
                              0 = default                                                                            */
-    int stack_rows;       /* hidden stack of a many-row predict: 0 = default: from loc_stack_rows_min_rows() (1280) rows per chunk
-                             the fp32 matrix pipe - 16 or 32 rows per workgroup, whichever the measured time model puts ahead
-                             on this device's compute units (16-row tiles up to 4096 rows and at 8193..12288 on 256 units) -
-                             and 2 rows per workgroup on the vector ALU below; 1 = the 32-row matrix-pipe form for every
-                             chunk; 2 = the 16-row form for every chunk; -1 = never (measurement switch)                    */
+    int stack_rows;       /* hidden stack of a many-row predict: 0 = default: from loc_stack_rows_min_rows() (8 x compute units + 1)
+                             rows per chunk the fp32 matrix pipe - 16 or 32 rows per workgroup, whichever the measured time
+                             model puts ahead on this device (16-row tiles up to 4096 rows and at 8193..12288 on 256 units) -
+                             and 2, 4 or 8 rows per workgroup on the vector ALU below (the fewest that keep the rows in one
+                             round of workgroups); 1 = the 32-row matrix-pipe form for every chunk; 2 = the 16-row form for
+                             every chunk; -1 / -2 / -3 = always 2 / 4 / 8 rows per workgroup on the vector ALU
+                             (measurement switches)                                                                       */
     int gemm_reduce;      /* many-row predicts on the int8 pipe: 0 = default: the SNP-group sum + shift + b1 + ELU of the layer-1
                              GEMM is its own launch (l1_gemm_reduce_kernel); 1 = it happens in the input stage of the
                              hidden-stack launch instead (loc_l1_forward_gemm_i8_partial + loc_stack_forward_eval_partial: same
@@ -435,9 +437,10 @@ int loc_stack_forward_eval_partial(const float* partial, int groups, int64_t gro
 /* Both inference entry points take MANY rows (>= loc_stack_rows_min_rows(), padded width 256) through stack_rows.hip: 32 rows
  * per workgroup on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: fp32 products and sums, the weights streamed once per 32
  * rows), or 16 rows per workgroup (v_mfma_f32_16x16x4_f32) where 32-row tiles would leave compute units idle (up to 4096
- * rows on 256 compute units, and 8193..12288), instead of 2 rows per workgroup on the vector ALU.  rows_form (loc_stack_forward_eval_form /
+ * rows on 256 compute units, and 8193..12288), instead of 2 / 4 / 8 rows per workgroup on the vector ALU (up to 8 x compute
+ * units rows).  rows_form (loc_stack_forward_eval_form /
  * loc_stack_forward_eval_partial; loc_tuning.stack_rows in loc_predict): 0 = by row count, 1 = always the 32-row form where
- * supported, 2 = always the 16-row form, -1 = never.  Same arithmetic, different summation order: predictions agree to fp32
+ * supported, 2 = always the 16-row form, -1 / -2 / -3 = 2 / 4 / 8 rows per workgroup on the vector ALU.  Same arithmetic, different summation order: predictions agree to fp32
  * round-off (tests/test_gpu_stack_rows.py). */
 int loc_stack_rows_supported(int Hp, int L);
 int loc_stack_rows_min_rows(void);

@@ -119,6 +119,7 @@ int sr_eval_launch(const float* a1, const float* rd_partial, int rd_G, int64_t r
                    const float* Wh, const float* bh, const float* wa, const float* ba, const float* wb, const float* bb, int L,
                    int n_b, const int32_t* rows, const float* Y, float* yhat, float* dist, int tile_rows, void* stream);
 extern "C" int loc_stack_rows_min_rows(void);
+int sr_compute_units();   // compute units of the current device (cached per device; 256 when there is none)
 extern "C" int loc_stack_rows_supported(int Hp, int L);
 
 // l1_kernels.hip: the layer-1 reduction alone (partial sums of G groups -> a1, optional Dropout on a1)

@@ -394,14 +394,21 @@ static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, in
                           const float* rd_b1, const float* Wh, const float* bh, const float* wa, const float* ba,
                           const float* wb, const float* bb, int Hp, int L, int n_b, const int32_t* rows, const float* Y,
                           float* yhat, float* dist, void* stream, int rows_form = 0) {
-    // many rows: 32 or 16 rows per workgroup on the fp32 matrix pipe (stack_rows.hip) instead of 2 rows per workgroup on the
-    // vector ALU; rows_form: 0 = by row count, 1 = always the 32-row form (where supported), 2 = always the 16-row form,
-    // -1 = never (measurement / tests)
+    // rows_form: 0 = by row count (width 256: 2, 4 or 8 rows per workgroup on the vector ALU while one round of workgroups
+    // covers the rows, above 8 x compute units rows 16 or 32 rows per workgroup on the fp32 matrix pipe, stack_rows.hip: the
+    // measured round times are there); 1 = always the 32-row matrix-pipe form (where supported), 2 = always the 16-row form;
+    // -1 = always 2 rows per workgroup on the vector ALU, -2 = 4 rows, -3 = 8 rows (measurement / tests)
     if (rows_form >= 0 && loc_stack_rows_supported(Hp, L) && (rows_form > 0 || n_b >= loc_stack_rows_min_rows()))
         return sr_eval_launch(a1, rd_partial, rd_G, rd_MH, rd_cvec8, rd_b1, Wh, bh, wa, ba, wb, bb, L, n_b, rows, Y, yhat, dist,
                               rows_form == 1 ? 32 : rows_form == 2 ? 16 : 0, stream);
     const loc_tuning* tune = nullptr;
-    const int nblk = (n_b + SF_R - 1) / SF_R;
+    int rpw = SF_R;
+    if (Hp == 256) {
+        const int cu = sr_compute_units();
+        if (rows_form == -2 || (rows_form == 0 && n_b > 2 * cu && n_b <= 4 * cu)) rpw = 4;
+        else if (rows_form == -3 || (rows_form == 0 && n_b > 4 * cu)) rpw = 8;
+    }
+    const int nblk = (n_b + rpw - 1) / rpw;
     // Workers + warm-up helpers of one launch should be co-resident (32 CUs per XCD): with more row groups
     // than one XCD holds, spread them over 2, 4 or all 8 XCDs (stride 4, 2, 1) instead of running in rounds.
     int xs = sf_xcd_stride(tune);
@@ -411,14 +418,18 @@ static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, in
         nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);      // the same number of helpers on every XCD in use
     }
     if (xs == 1) nh = 0;
-#define LAUNCH(N)                                                                                                 \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,         \
+#define LAUNCH_R(N, RR)                                                                                           \
+    hipLaunchKernelGGL((stack_fused_kernel<N, RR, false>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,           \
                        (hipStream_t)stream, a1, Wh, (const float*)nullptr, bh, wa, ba, wb, bb,                    \
                        (const uint8_t*)nullptr, 1.f, L, 0, n_b, rows, Y, (float*)nullptr, (float*)nullptr,        \
                        (float*)nullptr, (float*)nullptr, yhat, dist, xs, nblk, 32, rd_partial, rd_G, rd_MH, rd_cvec8,  \
                        rd_b1);
-    SF_SWITCH(LAUNCH)
+#define LAUNCH(N) LAUNCH_R(N, SF_R)
+    if (rpw == 4) { LAUNCH_R(8, 4) }
+    else if (rpw == 8) { LAUNCH_R(8, 8) }
+    else { SF_SWITCH(LAUNCH) }
 #undef LAUNCH
+#undef LAUNCH_R
     LOC_CHECK_LAUNCH();
     return 0;
 }

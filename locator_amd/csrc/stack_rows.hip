@@ -413,19 +413,21 @@ __global__ __launch_bounds__(512, CS == 4 ? 2 : 1) void stack_rows16_eval_kernel
 }
 
 
-// Rows from which the MFMA forms beat the row-parallel vector-ALU kernel: a workgroup's nine dependent layers take their time
-// whatever the row count.  Measured on 256 compute units (tools/stack_rows_bench.py, profiles/r05_stack_rows_bench*.jsonl):
-//   vector ALU, 2 rows per workgroup    0.047 us per row (53.8 us at 1024 rows, 78.8 at 1536)
-//   32-row tiles, one per compute unit   103-106 us per round of workgroups (8192 rows)
-//   16-row tiles, two per compute unit   64 us up to one workgroup per compute unit (4096 rows), then + 50-55 us per further
-//                                        4096 rows (110 us at 8192, 165 at 12,288, 216 at 16,384)
-// The launcher takes the matrix-pipe form with the smaller modelled time: 16-row tiles up to 4096 rows and at 8193..12,288,
-// 32-row tiles at 4097..8192 and 12,289..16,384 (a predict chunk is at most 16,384 rows).
-#define SR_MIN_ROWS 1280
+// Which form takes how many rows: a workgroup's nine dependent layers take their time whatever the row count, so what counts
+// is the time of a ROUND of workgroups (one - or for the 16-row tiles two - per compute unit) and how many rows it covers.
+// Measured on 256 compute units (tools/stack_rows_bench.py, profiles/r05_stack_rows_bench*.jsonl):
+//   vector ALU (stack_fused.hip), 2 rows per workgroup   26-29 us per round (512 rows)      -> up to 2 x CUs rows
+//   vector ALU, 4 rows per workgroup                     30-33 us per round (1024 rows)     -> up to 4 x CUs rows
+//   vector ALU, 8 rows per workgroup                     45-48 us per round (2048 rows)     -> up to 8 x CUs rows
+//   16-row tiles, two per compute unit                   64 us up to one workgroup per compute unit (4096 rows), then + 50-55
+//                                                        us per further 4096 rows (110 us at 8192, 165 at 12,288, 216 at 16,384)
+//   32-row tiles, one per compute unit                   103-106 us per round (8192 rows)
+// Above 8 x CUs rows the launcher takes the matrix-pipe form with the smaller modelled time: 16-row tiles up to 4096 rows and
+// at 8193..12,288, 32-row tiles at 4097..8192 and 12,289..16,384 (a predict chunk is at most 16,384 rows).
 #define SR16_FIRST_US 12
 #define SR16_ROUND_US 52
 #define SR32_ROUND_US 105
-static int sr_compute_units() {
+int sr_compute_units() {
     static int ncu[LOC_MAX_DEVICES] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -442,7 +444,7 @@ static bool sr_takes_16_row_tiles(int n_b) {
     const int r16 = ((n_b + 15) / 16 + cu - 1) / cu, r32 = ((n_b + 31) / 32 + cu - 1) / cu;
     return SR16_FIRST_US + r16 * SR16_ROUND_US < r32 * SR32_ROUND_US;
 }
-extern "C" int loc_stack_rows_min_rows(void) { return SR_MIN_ROWS; }
+extern "C" int loc_stack_rows_min_rows(void) { return 8 * sr_compute_units() + 1; }
 extern "C" int loc_stack_rows_supported(int Hp, int L) { return Hp == SR_HP && L >= 2; }
 
 #ifdef SR_STAMPS

@@ -1,6 +1,7 @@
 """The many-row forms of the hidden stack (stack_rows.hip: 32 rows per workgroup on v_mfma_f32_32x32x2_f32, and - round 5 -
 16 rows per workgroup on v_mfma_f32_16x16x4_f32 where that needs fewer rounds of workgroups: up to 4096 rows per chunk) against
-the row-parallel vector-ALU kernel they replace for >= 1280 rows and against the float64 forward of the oracle
+the row-parallel vector-ALU kernel (2, 4 or 8 rows per workgroup) they replace above 8 x compute units rows and against the
+float64 forward of the oracle
 (locator.py:319-325 layers 2..L + the two Dense(2) heads; model.predict, :414, :441)."""
 import ctypes as C
 
@@ -45,7 +46,7 @@ def _run(net, a1_dev, n, form, with_dist):
 
 @pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("n,width,nlayers", [(2, 256, 10), (15, 256, 3), (16, 256, 10), (17, 256, 2), (31, 256, 10), (32, 256, 2),
-                                             (33, 250, 4), (100, 256, 10), (1280, 256, 10), (3072, 256, 10), (3300, 256, 10), (4096, 230, 3),
+                                             (33, 250, 4), (100, 256, 10), (600, 256, 10), (1280, 256, 10), (3072, 256, 10), (3300, 256, 10), (4096, 230, 3),
                                              (8191, 256, 10)])
 def test_matrix_pipe_form_equals_the_vector_alu_form_and_the_oracle(n, width, nlayers, form):
     """form 1 = 32-row tiles, form 2 = 16-row tiles (VERDICT r04 next #6: 3072 / 4096 / 8191 rows among the shapes)."""
@@ -63,9 +64,18 @@ def test_matrix_pipe_form_equals_the_vector_alu_form_and_the_oracle(n, width, nl
     assert maxerr(dist_m, O.euclid(ref, y)) < 2e-5 and maxerr(dist_m, dist_v) < 1e-5
     got_n, _ = _run(net, a1_dev, n, form, False)                  # without targets: same predictions
     assert np.array_equal(got_n, got_m)
-    if form == 2 and 1280 <= n <= 4096:                           # what the default picks for this row count
+    if form == 2 and 2049 <= n <= 4096:                           # what the default picks for this row count (256 compute units)
         got_d, _ = _run(net, a1_dev, n, 0, True)
         assert np.array_equal(got_d, got_m)
+    if form == 1 and width == 256:
+        # the vector-ALU form with 4 and 8 rows per workgroup (round 5: what the default takes for 513..1024 and 1025..2048
+        # rows on 256 compute units): a row's sums do not depend on how many rows share its workgroup
+        for rf in (-2, -3):
+            got_r, dist_r = _run(net, a1_dev, n, rf, True)
+            assert np.array_equal(got_r, got_v) and np.array_equal(dist_r, dist_v), rf
+        if n <= 2048:
+            got_d, _ = _run(net, a1_dev, n, 0, True)
+            assert np.array_equal(got_d, got_v)
 
 
 def test_only_width_256_takes_the_matrix_pipe_form():
@@ -73,12 +83,13 @@ def test_only_width_256_takes_the_matrix_pipe_form():
     lib = _lib.load()
     assert lib.loc_stack_rows_supported(256, 10) and lib.loc_stack_rows_supported(256, 2)
     assert not lib.loc_stack_rows_supported(128, 10) and not lib.loc_stack_rows_supported(256, 1)
-    assert lib.loc_stack_rows_min_rows() == 1280
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert lib.loc_stack_rows_min_rows() == 8 * ncu + 1         # up to 8 x CUs rows one round of vector-ALU workgroups covers them
 
 
 @pytest.mark.parametrize("n", [3072, 5000])
 def test_predict_through_both_forms_agrees(n):
-    """loc_predict: the default takes a matrix-pipe form from 1280 rows per chunk; loc_tuning.stack_rows = -1 keeps the
+    """loc_predict: the default takes a matrix-pipe form from 2049 rows per chunk; loc_tuning.stack_rows = -1 keeps the
     vector-ALU kernel.  Both against oracle.predict, int8 exact first layer with the group reduction fused into either."""
     x, y, p, rng = make_problem(700, 4000, 256, 10, seed=n)
     rows = torch.from_numpy((rng.permutation(n) % 700).astype(np.int32)).cuda()

@@ -32,7 +32,7 @@ def main():
         a1 = torch.randn(((n + 127) // 128 * 128, d.Hp), device=dev) * 0.5
         yhat = torch.zeros((n, 2), device=dev)
         rec = {"rows": n}
-        for form, name in ((-1, "valu_2rows"), (1, "mfma_32rows"), (2, "mfma_16rows"), (0, "default")):
+        for form, name in ((-1, "valu_2rows"), (-2, "valu_4rows"), (-3, "valu_8rows"), (1, "mfma_32rows"), (2, "mfma_16rows"), (0, "default")):
             run = lambda: _lib.check(lib.loc_stack_forward_eval_form(a1.data_ptr(), P + 4 * lay.wh, P + 4 * lay.bh, P + 4 * lay.wa,
                                                                      P + 4 * lay.ba, P + 4 * lay.wb, P + 4 * lay.bb, d.Hp, d.L, n,
                                                                      None, None, yhat.data_ptr(), None, form,
