@@ -282,6 +282,8 @@ def main():
     ap.add_argument("--replicates-per-gpu", type=int, default=1, help="independent fits per process on separate streams")
     ap.add_argument("--nt-mask", type=int, default=0, help="loc_tuning.l1b_nt_mask (cache-policy measurement switch)")
     ap.add_argument("--stack-helpers", type=int, default=0, help="loc_tuning.stack_helpers (L2 warm-up workgroups of the hidden stack; measurement switch)")
+    ap.add_argument("--stack-xcd-stride", type=int, default=0, help="loc_tuning.stack_xcd_stride (1, 2, 4, 8: the hidden stack's workers share 8 / n XCDs; measurement switch)")
+    ap.add_argument("--stack-train-rows", type=int, default=0, help="loc_tuning.stack_train_rows (1, 2, 4 batch rows per workgroup of the training stack; 0 = default)")
     ap.add_argument("--separate-tail", action="store_true",
                     help="measurement switch (loc_tuning.chain_tail = -1): the hidden-layer Adam tail of a chained step as "
                          "its own launch instead of trailing workgroups of the chained layer-1 launch")
@@ -366,7 +368,9 @@ def main():
             self.net = LocatorNet(X, Y, K, H, 10, 0.25, seed=12345, replicate=replicate, device=dev,
                                   tuning=({"l1b_nt_mask": args.nt_mask} if args.nt_mask else {}) |
                                          ({"chain_tail": -1} if args.separate_tail else {}) |
-                                         ({"stack_helpers": args.stack_helpers} if args.stack_helpers else {}))
+                                         ({"stack_helpers": args.stack_helpers} if args.stack_helpers else {}) |
+                                         ({"stack_xcd_stride": args.stack_xcd_stride} if args.stack_xcd_stride else {}) |
+                                         ({"stack_train_rows": args.stack_train_rows} if args.stack_train_rows else {}))
             if args.l1_bwd_grid:
                 self.net.l1_bwd_grid = int(args.l1_bwd_grid)
             # the product's epoch loop (locator_amd/train.py FitLoop): callbacks on the device, epochs enqueued ahead of it.

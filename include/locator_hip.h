@@ -116,6 +116,10 @@ typedef struct loc_tuning {
     int chain_tail;       /* chained steps (loc_train_step_chain): 0 = default: the step's hidden-layer / head Adam tail runs
                              as trailing workgroups of the chained layer-1 launch (they fill the compute units that finish
                              their k-tiles an iteration early); -1 = its own launch after it (measurement switch)          */
+    int stack_train_rows; /* batch rows per workgroup of the fused hidden stack of a TRAINING step: 0 = default: 1 (32 workers +
+                             helpers over two XCDs for a 32-row step: measured 162 against 171 us per step at the metric's
+                             shape - a worker is bound by its 4.7 MB weight stream, halving its rows' arithmetic shortens
+                             what does not overlap with it); 1, 2 (rounds 1-4) or 4 = that many (measurement switch)         */
 } loc_tuning;
 
 /* Everything a training / inference step needs.  All device pointers. */

@@ -40,7 +40,8 @@ class Layout(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("stack_helpers", C.c_int), ("stack_xcd_stride", C.c_int), ("l1b_nt_mask", C.c_int),
-                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("stack_rows", C.c_int), ("gemm_reduce", C.c_int), ("chain_tail", C.c_int)]
+                ("l1b_rows", C.c_int), ("rows_rt", C.c_int), ("gemm_i8_unit_tiles", C.c_int), ("stack_rows", C.c_int), ("gemm_reduce", C.c_int), ("chain_tail", C.c_int),
+                ("stack_train_rows", C.c_int)]
 
 
 class Net(C.Structure):

@@ -347,6 +347,17 @@ extern "C" int loc_transpose_hidden(const float* Wh, float* WhT, int Hp, int n_h
 }
 
 constexpr int SF_R = 2;   // batch rows per workgroup -> 16 workgroups per 32-row block
+// rows per workgroup of the TRAINING launch (loc_tuning.stack_train_rows).  A worker is bound by its weight stream (4.7 MB of
+// Wh + WhT from its XCD's L2, ~43 us at 110 GB/s per compute unit) whatever its row count, and the rows' arithmetic that does
+// not overlap with the stream comes on top: measured at the metric's shape (bench.py, 32-row steps, 12 helpers) 4 rows per
+// workgroup 189.9 us per step, 2 rows (rounds 1-4) 171.3, 1 row 162.4 (32 workers + helpers over two XCDs) - same bits.
+// One row per workgroup is ahead at every shape tried (profiles/r05_stack_train_rows.log): widths 64 / 128 / 512 +4 %,
+// 5,830 SNPs +10 %, 20,000 +9 %, 500,000 +1 %, --batch_size 64 +1.7 %, 128 +0.8 %.
+static int sf_train_rows(const loc_tuning* tune, int n_b) {
+    const int v = tune ? tune->stack_train_rows : 0;
+    (void)n_b;
+    return (v == 1 || v == 2 || v == 4) ? v : 1;
+}
 
 // L2 warm-up helper workgroups and XCD placement stride of the fused stack: speed hints (loc_tuning), defaults
 // measured at width 256: helpers 0 -> 78.6 us, 4 -> 63, 8 -> 51.7, 12 -> 51.0, 32 -> 55
@@ -371,7 +382,8 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
     }
     // every row of the row blocks in use is carried (rows >= n_b get a zero loss gradient), so the tail and the
     // layer-1 backward can contract whole 32-row blocks
-    const int nblk = (n_b + 31) / 32 * (32 / SF_R);
+    const int rpw = sf_train_rows(tune, n_b);
+    const int nblk = (n_b + 31) / 32 * (32 / rpw);
     int xs = sf_xcd_stride(tune);
     int nh = xs > 1 ? sf_helpers(tune) : 0;
     while (xs > 1 && (nblk + nh + 8 / xs - 1) / (8 / xs) > 32) {     // more row groups than one XCD holds
@@ -379,13 +391,19 @@ extern "C" int loc_stack_forward_backward(const float* a1_in, const float* Wh, c
         nh = (nh + 8 / xs - 1) / (8 / xs) * (8 / xs);
     }
     if (xs == 1) nh = 0;
-#define LAUNCH(N)                                                                                                  \
-    hipLaunchKernelGGL((stack_fused_kernel<N, SF_R, true>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,           \
+#define LAUNCH_TR(N, RR)                                                                                           \
+    hipLaunchKernelGGL((stack_fused_kernel<N, RR, true>), dim3((nblk + nh) * xs), dim3(SF_THREADS), 0,             \
                        (hipStream_t)stream, a1_in, Wh, WhT, bh, wa, ba, wb, bb, mask, keep_scale, L, n_pre, n_b,  \
                        rows, Y, acts, adrop, dz, head_out, (float*)nullptr, (float*)nullptr, xs, nblk, slot_rows,         \
                        (const float*)nullptr, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr);
-    SF_SWITCH(LAUNCH)
-#undef LAUNCH
+#define LAUNCH1(N) LAUNCH_TR(N, 1)
+#define LAUNCH2(N) LAUNCH_TR(N, 2)
+#define LAUNCH4(N) LAUNCH_TR(N, 4)
+    if (rpw == 1) { SF_SWITCH(LAUNCH1) } else if (rpw == 4) { SF_SWITCH(LAUNCH4) } else { SF_SWITCH(LAUNCH2) }
+#undef LAUNCH1
+#undef LAUNCH2
+#undef LAUNCH4
+#undef LAUNCH_TR
     LOC_CHECK_LAUNCH();
     return 0;
 }
@@ -427,6 +445,7 @@ static int sf_eval_launch(const float* a1, const float* rd_partial, int rd_G, in
 #define LAUNCH(N) LAUNCH_R(N, SF_R)
     if (rpw == 4) { LAUNCH_R(8, 4) }
     else if (rpw == 8) { LAUNCH_R(8, 8) }
+
     else { SF_SWITCH(LAUNCH) }
 #undef LAUNCH
 #undef LAUNCH_R
