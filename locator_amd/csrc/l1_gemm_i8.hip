@@ -628,14 +628,28 @@ __global__ __launch_bounds__(G8_NT / UT) void l1_gemm_i8_kernel(const uint8_t* _
     c.lane = lane;
     c.jl = lane & 31;
     c.hi = lane >> 5;
+    // (row tile, SNP group) of this workgroup.  Workgroup b runs on XCD b % 8 (observed dispatch; a speed hint only), and the
+    // workgroups that share a SNP group - the same weight tiles, different row tiles - should share an XCD's L2.
+    //   G a multiple of 8: XCD x takes the groups x, x + 8, ... whole (rounds 3-4).
+    //   any other G (round 5): the n_mt x G pairs, ordered group-major, are cut into eight contiguous runs of equal length
+    //   (+- 1), one per XCD; the k-th workgroup of an XCD takes the k-th pair of its run, surplus workgroups (the grid is 8 x
+    //   the longest run) leave at once.  Rounds 3-4 rounded G DOWN to a multiple of 8 instead and left up to 37 % of the
+    //   compute units idle at in-between row counts: 2500 rows = 20 row tiles x 8 groups = 160 workgroups, now 20 x 12 = 240:
+    //   155 -> 124 us; 3000 rows 163 -> 146; 1500 rows 79 -> 75 (same box, profiles/r05_gemm_group_mapping.log).  For
+    //   multiples of 8 the run form measured 2 % slower at 1000 rows (56.6 against 55.4 us) and equal elsewhere, so they
+    //   keep the strided form.
     int mt, g;
     if ((G & 7) == 0) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         mt = idx % n_mt;
         g = xcd + 8 * (idx / n_mt);
     } else {
-        g = blockIdx.x % G;
-        mt = blockIdx.x / G;
+        const int P = n_mt * G, x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int s0 = (int)((int64_t)x * P / 8), s1 = (int)((int64_t)(x + 1) * P / 8);
+        if (k >= s1 - s0) return;
+        const int pr = s0 + k;
+        g = pr / n_mt;
+        mt = pr - g * n_mt;
     }
     // group g owns a CONTIGUOUS run of pairs (balanced to within one): a workgroup then walks each of its 128 genotype
     // rows sequentially, which HBM serves at 6.0 TB/s where the interleaved assignment of l1_gemm.hip (every G-th pair)
@@ -849,7 +863,6 @@ static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, in
     const int64_t cap = partial_floats / ((int64_t)Mp * G8_HP);
     if (G > cap) G = (int)cap;
     if (G > nkt / 2) G = nkt / 2;
-    if (G >= 8) G &= ~7;
     if (G < 1) { loc_set_error("loc_l1_forward_gemm_i8: scratch too small for %d rows", n); return -1; }
     // an i32 accumulator holds sum_k x d with |d| <= 128 over one group's SNPs
     const int64_t snps_per_group = (int64_t)((nkt / 2 + G - 1) / G) * 2 * G8_BK;
@@ -863,15 +876,16 @@ static int g8_forward(const uint8_t* X, int64_t x_pitch, const int32_t* rows, in
     const float* delta = reinterpret_cast<const float*>(base + g8_delta_off());
     const unsigned char* tiles = base + g8_tiles_off(d);
     hipStream_t st = (hipStream_t)stream;
+    const int g8_grid = 8 * ((n_mt * G + 7) / 8);       // eight runs of pairs, the longest decides (see the kernel)
 #define G8_LAUNCH(DTV, UTV)                                                                                     \
     {                                                                                                           \
         if (packed) {                                                                                           \
             LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, 1, true>), G8_LDS_PK);                                       \
-            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, 1, true>), dim3(n_mt * G), dim3(G8_NT), G8_LDS_PK, st, X,    \
+            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, 1, true>), dim3(g8_grid), dim3(G8_NT), G8_LDS_PK, st, X,     \
                                x_pitch, rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);               \
         } else {                                                                                                \
             LOC_ENSURE_LDS((l1_gemm_i8_kernel<DTV, UTV, false>), G8_LDS);                                       \
-            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, UTV, false>), dim3(n_mt * G), dim3(G8_NT / UTV), G8_LDS, st, X, \
+            hipLaunchKernelGGL((l1_gemm_i8_kernel<DTV, UTV, false>), dim3(g8_grid), dim3(G8_NT / UTV), G8_LDS, st, X, \
                                x_pitch, rows, n, d->Kp, tiles, delta, partial, G, n_mt, nkt / 2);               \
         }                                                                                                       \
     }
