@@ -27,7 +27,9 @@ def _kernels(source, pattern):
     text = open(out).read()
     shutil.rmtree(os.path.dirname(out), ignore_errors=True)
     res = {}
-    for m in re.finditer(r"^(_Z\w+):\s.*?^\s*s_endpgm", text, re.S | re.M):
+    # a kernel = its label up to the end-of-function marker (NOT the first s_endpgm: a workgroup that leaves early - the surplus
+    # workgroups of l1_gemm_i8_kernel's group mapping, round 5 - has one in the middle of the function)
+    for m in re.finditer(r"^(_Z\w+):\s.*?^\.Lfunc_end\d+:", text, re.S | re.M):
         if re.search(pattern, m.group(1)):
             res[m.group(1)] = m.group(0).splitlines()
     return res
