@@ -14,7 +14,9 @@
 #include "common.h"
 #include "stack_tail.h"
 
+#ifndef SF_THREADS
 #define SF_THREADS 512
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for
 // the weight prefetch that is deliberately kept in flight across the reduction phases.  Inside
