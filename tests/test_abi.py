@@ -42,11 +42,13 @@ def test_ctypes_structs_follow_the_header_field_for_field(repo_root):
     """loc_net / loc_dims / loc_layout in include/locator_hip.h, the ctypes Structures in locator_amd/_lib.py
     and the stub shown in INTEGRATION.md must list the same fields in the same order."""
     src = open(os.path.join(repo_root, "include", "locator_hip.h")).read()
-    for cname, ctype in (("loc_dims", _lib.Dims), ("loc_layout", _lib.Layout), ("loc_net", _lib.Net)):
+    for cname, ctype in (("loc_dims", _lib.Dims), ("loc_layout", _lib.Layout), ("loc_net", _lib.Net), ("loc_tuning", _lib.Tuning)):
         assert _struct_fields(src, cname) == [f[0] for f in ctype._fields_], cname
     doc = open(os.path.join(repo_root, "INTEGRATION.md")).read()
     stub = re.search(r"class Net\(C\.Structure\):\s*_fields_ = \[(.*?)\]\n", doc, flags=re.S).group(1)
     assert re.findall(r'\("([a-z_0-9A-Z]+)"', stub) == [f[0] for f in _lib.Net._fields_]
+    tstub = re.search(r"class Tuning\(C\.Structure\): _fields_ = \[\(n, C\.c_int\) for n in \((.*?)\)\]", doc).group(1)
+    assert re.findall(r'"([a-z_0-9A-Z]+)"', tstub) == [f[0] for f in _lib.Tuning._fields_]
     # pointer / int64 / int / float members only: the natural-alignment size is what both compilers produce
     assert C.sizeof(_lib.Net) % 8 == 0
 
