@@ -80,8 +80,10 @@ def build_parser():
     # --- additions of this implementation (kept last so the reference's keys keep their order)
     p.add_argument("--gpus", default=None, type=int,
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
-    p.add_argument("--fits_per_gpu", default=2, type=int,
-                   help="concurrent replicate fits per GPU for --windows / --bootstrap (default 2)")
+    p.add_argument("--fits_per_gpu", default=0, type=int,
+                   help="concurrent replicate fits per GPU for --windows / --bootstrap (default 0 = by SNP count: 3 up to "
+                        "50,000 SNPs per fit, 2 above - measured 903k / 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k / 226k "
+                        "at 100,000)")
     p.add_argument("--procs_per_gpu", default=1, type=int,
                    help="worker processes per GPU for --windows / --bootstrap (default 1): the --fits_per_gpu concurrent fits "
                         "of a GPU run as that many threads of ONE process, each on its own stream - one device context, "
@@ -478,14 +480,53 @@ _BASE_CACHE = {}      # per worker process: the shared genotype rows, uploaded o
 _BASE_LOCK = __import__("threading").Lock()
 
 
+AUTO_FITS_MAX = 3                # fit threads per GPU under --fits_per_gpu 0 ...
+AUTO_FITS_SNPS = 50_000          # ... of which three fit at a time up to this many SNPs per fit, two above: the hidden stack of
+#                                  a fit is latency-bound on a few compute units and a third fit fills them while layer 1 is
+#                                  short (bench.py --replicates-per-gpu 1 / 2 / 3 / 4, samples/s: 5,830 SNPs 421k / 711k / 903k /
+#                                  699k; 20,000 SNPs 354k / 529k / 620k / 513k; 100,000 SNPs 190k / 226k / 221k / 212k)
+_FIT_SLOTS = {}
+_FIT_SLOTS_LOCK = __import__("threading").Lock()
+
+
+def _fit_slots(device, K):
+    """Semaphore that admits the concurrent fits of this process on `device` (created at the first unit, from its SNP count)."""
+    import threading
+    with _FIT_SLOTS_LOCK:
+        if device not in _FIT_SLOTS:
+            n = int(getattr(args, "fits_per_gpu", 0) or 0)
+            if n <= 0:
+                n = AUTO_FITS_MAX if K <= AUTO_FITS_SNPS else 2
+            _FIT_SLOTS[device] = threading.BoundedSemaphore(max(1, n))
+        return _FIT_SLOTS[device]
+
+
+def _snps_hint(unit):
+    """SNP count of a unit's fit before anything has been filtered: a bootstrap unit's matrix is there, a window unit knows
+    its variant range (an upper bound: the filters only remove)."""
+    if "traingen" in unit:
+        return int(np.shape(unit["traingen"])[1])
+    if "gt_shape" in unit:
+        return int(unit["gt_shape"][0])
+    if "window" in unit:
+        return int(unit["window"][1] - unit["window"][0])
+    return 0
+
+
 def _fit_unit(unit, device="cuda:0"):
     """_fit_unit_body under the process-wide device lock (train.DEVICE_LOCK): when several fits share a process, one thread
     and stream each, everything a fit does on the device outside its epoch loop - upload, net construction, read-backs,
     predict, and the destruction of its graphs / events / buffers when the body returns - is kept apart from a sibling's
-    HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run)."""
+    HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run).  Before that the unit waits for one of
+    the process's fit slots (_fit_slots: --fits_per_gpu, or 3 / 2 by SNP count) - without holding the lock."""
     from .train import DEVICE_LOCK
-    with DEVICE_LOCK:
-        return _fit_unit_body(unit, device)
+    slots = _fit_slots(device, _snps_hint(unit))
+    slots.acquire()
+    try:
+        with DEVICE_LOCK:
+            return _fit_unit_body(unit, device)
+    finally:
+        slots.release()
 
 
 def _fit_unit_body(unit, device="cuda:0"):
@@ -767,7 +808,9 @@ def main(argv=None):
         # the worker processes start NOW: spawn + `import torch` + device context + library load overlap the parent's
         # own prologue instead of following it
         lazy_windows = args.windows and not args.impute_missing and args.max_SNPs is None
-        pool = replicates.ReplicatePool(args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu,
+        # --fits_per_gpu 0 (default): the pool gets AUTO_FITS_MAX fit threads per GPU and _fit_unit admits as many of them at a
+        # time as the SNP count of the fits asks for (the pool exists before the genotypes have been read)
+        pool = replicates.ReplicatePool(args, _fit_unit, n_gpus=args.gpus, fits_per_gpu=args.fits_per_gpu or AUTO_FITS_MAX,
                                         host_prepare=_load_window_on_loader_thread if lazy_windows else None,
                                         unit_timeout=getattr(args, "unit_timeout", 0),
                                         max_workers=_unit_count_bound(),
