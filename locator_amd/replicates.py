@@ -362,7 +362,7 @@ class ReplicatePool:
         small, descs, handles = _share(shared)
         workers = self.workers
         state = {"got": 0, "next": 0}
-        retry, attempts = deque(), {}
+        retry, crashed = deque(), set()          # crashed: units that were fitting (or first in line) when a worker was lost
 
         def record(r):
             i = r["unit_index"]
@@ -394,13 +394,19 @@ class ReplicatePool:
                     conn.send(("shared", small, descs))
                     w["shared_sent"] = True
                 while len(w["inflight"]) < self.depth:
+                    if w.get("exclusive") is not None:
+                        return                       # a crash suspect has this worker to itself
                     i = next_index()
                     if i is None:
                         return
+                    if i in crashed:                 # lost a worker once: its second try runs ALONE, so that if it is the
+                        if w["inflight"]:            # one that kills workers it takes nothing else with it
+                            retry.appendleft(i)
+                            return
+                        w["exclusive"] = i
                     if not w["inflight"]:
                         w["t_wait"] = time.time()    # an idle worker starts waiting for this unit's host work now
                     w["inflight"].append(i)
-                    attempts[i] = attempts.get(i, 0) + 1
                     tl["units"].setdefault(i, {}).update(gpu=w["gpu"], dispatched=time.time())
                     conn.send(("unit", i, units[i]))
             except (OSError, ValueError):        # the worker vanished between two messages: its units go back
@@ -408,8 +414,11 @@ class ReplicatePool:
 
         def bury(conn, why, culprit=None):
             """The worker behind `conn` is gone.  culprit = the unit known to have caused it (the one that timed out): an error
-            record at once.  Every other unit it held - fitting on a sibling thread, or only prefetched - goes back to the
-            queue and fails only when a SECOND worker is lost with it in hand (a crash does not say which fit thread aborted)."""
+            record at once, and everything else it held goes back to the queue as it is.  Without a culprit (a crash does not say
+            which fit thread aborted) the units that were FITTING - or, if none was, the first in line, whose host work was
+            running - become suspects: each gets one more try, alone on a worker, and fails when that worker is lost too; units
+            that were only prefetched go back uncounted.  So a unit that kills workers costs two workers and nothing else, and
+            an innocent sibling of it always completes."""
             w = workers.pop(conn, None)
             if w is None:
                 return
@@ -418,14 +427,17 @@ class ReplicatePool:
             except OSError:
                 pass
             w["p"].join(5)
+            suspects = set(w["active"]) if w["active"] else set(w["inflight"][:1])
             for i in w["inflight"]:
                 if out[i] is not None:
                     continue
-                if i == culprit or attempts.get(i, 0) >= 2:
-                    what = "while fitting this unit" if (i in w["active"] or i == culprit) else "twice with this unit in hand"
+                if i == culprit or (culprit is None and i in suspects and i in crashed):
+                    what = "while fitting this unit" + (" (second worker lost)" if i in crashed else "")
                     record({"name": units[i].get("name", "?"), "unit_index": i, "gpu": w["gpu"],
                             "error": f"worker process died ({why}, exit code {w['p'].exitcode}) {what}"})
                 else:
+                    if culprit is None and i in suspects:
+                        crashed.add(i)
                     retry.append(i)                      # another worker (or the replacement) takes it
             if not w["inflight"] and why not in ("retired",):
                 self.failed_starts += 1
@@ -466,6 +478,8 @@ class ReplicatePool:
                         w["active"][payload] = time.time()
                         tl["units"].setdefault(payload, {})["started"] = w["active"][payload]
                     elif kind == "done":
+                        if w.get("exclusive") == payload["unit_index"]:
+                            w["exclusive"] = None
                         if payload["unit_index"] in w["inflight"]:
                             w["inflight"].remove(payload["unit_index"])
                         w["active"].pop(payload["unit_index"], None)
