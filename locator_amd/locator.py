@@ -82,7 +82,7 @@ def build_parser():
                    help="GPUs used to shard --windows / --bootstrap replicates (default: all visible)")
     p.add_argument("--fits_per_gpu", default=0, type=int,
                    help="concurrent replicate fits per GPU for --windows / --bootstrap (default 0 = by SNP count: 3 up to "
-                        "50,000 SNPs per fit, 2 above - measured 903k / 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k / 226k "
+                        "70,000 SNPs per fit, 2 above - measured 903k / 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k / 226k "
                         "at 100,000)")
     p.add_argument("--procs_per_gpu", default=1, type=int,
                    help="worker processes per GPU for --windows / --bootstrap (default 1): the --fits_per_gpu concurrent fits "
@@ -481,10 +481,11 @@ _BASE_LOCK = __import__("threading").Lock()
 
 
 AUTO_FITS_MAX = 3                # fit threads per GPU under --fits_per_gpu 0 ...
-AUTO_FITS_SNPS = 50_000          # ... of which three fit at a time up to this many SNPs per fit, two above: the hidden stack of
+AUTO_FITS_SNPS = 70_000          # ... of which three fit at a time up to this many SNPs per fit, two above: the hidden stack of
 #                                  a fit is latency-bound on a few compute units and a third fit fills them while layer 1 is
 #                                  short (bench.py --replicates-per-gpu 1 / 2 / 3 / 4, samples/s: 5,830 SNPs 421k / 711k / 903k /
-#                                  699k; 20,000 SNPs 354k / 529k / 620k / 513k; 100,000 SNPs 190k / 226k / 221k / 212k)
+#                                  699k; 20,000 SNPs 354k / 529k / 620k / 513k; 100,000 SNPs 190k / 226k / 221k / 212k; 2 against 3
+#                                  fits at 35,000 / 50,000 / 65,000 / 80,000 SNPs: 430k / 490k, 356k / 402k, 307k / 324k, 269k / 270k)
 _FIT_SLOTS = {}
 _FIT_SLOTS_LOCK = __import__("threading").Lock()
 

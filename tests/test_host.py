@@ -441,14 +441,14 @@ def test_device_lock_is_reentrant_per_thread_and_released_drops_the_whole_hold()
 
 def test_fit_slots_admit_three_small_fits_or_two_large_ones_unless_the_flag_says_otherwise(monkeypatch):
     """--fits_per_gpu 0 (the default since round 5): the pool starts three fit threads per GPU and locator._fit_unit admits
-    as many units at a time as their SNP count asks for - 3 up to 50,000 SNPs, 2 above (bench.py --replicates-per-gpu sweep:
+    as many units at a time as their SNP count asks for - 3 up to 70,000 SNPs, 2 above (bench.py --replicates-per-gpu sweep:
     903k against 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k against 226k at 100,000); an explicit flag wins."""
     class A:
         fits_per_gpu = 0
     monkeypatch.setattr(L, "args", A, raising=False)
     assert L._snps_hint({"window": (100, 1250)}) == 1150 and L._snps_hint({"gt_shape": (150016, 765, 2)}) == 150016
     assert L._snps_hint({"traingen": np.zeros((5, 77), np.uint8)}) == 77 and L._snps_hint({}) == 0
-    for K, flag, want in ((5830, 0, 3), (50_000, 0, 3), (50_001, 0, 2), (560_000, 0, 2), (5830, 1, 1), (560_000, 4, 4)):
+    for K, flag, want in ((5830, 0, 3), (70_000, 0, 3), (70_001, 0, 2), (560_000, 0, 2), (5830, 1, 1), (560_000, 4, 4)):
         monkeypatch.setattr(L, "_FIT_SLOTS", {})
         A.fits_per_gpu = flag
         sem = L._fit_slots("cuda:0", K)
