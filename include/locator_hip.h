@@ -236,6 +236,17 @@ int loc_dropout_mask_fill(uint8_t* mask, int64_t n, float p, uint64_t seed, uint
 /* Bootstrap resample of SNP columns (locator.py:648-653): dst[r][j] = src[r][site_order[j]]. */
 int loc_gather_columns(const uint8_t* src, int64_t src_pitch, const int32_t* site_order, int K,
                        uint8_t* dst, int64_t dst_pitch, int n_rows, void* stream);
+/* Replicate summarisation, the step right after --windows / --bootstrap (replaces kdepred + centroid of
+ * /root/reference/locator_py/plot_locator.py:26-44 and scripts/plot_locator.R:57-113): sample s owns the points
+ * xy[offsets[s] .. offsets[s+1]) ([x, y] pairs, float64, map units) = its replicate predictions.  Per sample:
+ *   out[4s+2], out[4s+3]  geographic centroid (mean of the points)
+ *   peak_index[s]         FIRST index of the maximum of the Gaussian kernel density estimate (bandwidth h) evaluated at the
+ *                         points themselves - sklearn KernelDensity(kernel='gaussian', bandwidth=h).score_samples + argmax
+ *   out[4s+0], out[4s+1]  that point.  A sample with a non-finite coordinate (or no points) has no estimate: peak_index -1
+ *                         and the centroid instead (the reference's `except` branch).
+ * One workgroup per sample, float64, fixed summation order (launch-independent results). */
+int loc_kde_peak_batch(const double* xy, const int64_t* offsets, int n_samples, double bandwidth, int32_t* peak_index,
+                       double* out, void* stream);
 /* out[0] = max(out[0], largest byte of X[0..n_rows)[0..K)) (uint32, zero it first): which number formats can carry the
  * genotypes exactly (int8 needs <= 127). */
 int loc_genotype_max(const uint8_t* X, int64_t x_pitch, int n_rows, int K, uint32_t* out, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "loc_init_uniform": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
     "loc_dropout_mask_fill": (C.c_int, [vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, vp]),
     "loc_gather_columns": (C.c_int, [vp, C.c_int64, vp, C.c_int, vp, C.c_int64, C.c_int, vp]),
+    "loc_kde_peak_batch": (C.c_int, [vp, vp, C.c_int, C.c_double, vp, vp, vp]),
     "loc_w1_swizzle": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "loc_w1_unswizzle": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "loc_bn_batch_stats": (C.c_int, [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -290,3 +290,88 @@ extern "C" int loc_snapshot_if(const loc_cb_state* state, const float* params, f
     LOC_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Replicate summarisation (the step right after --windows / --bootstrap): per sample, over its n replicate predictions,
+//   the geographic centroid = mean of the predictions                       (/root/reference/locator_py/plot_locator.py:39-44)
+//   the prediction with the highest Gaussian kernel density, bandwidth h, the density evaluated at the predictions
+//   themselves: sklearn KernelDensity(kernel='gaussian').fit(P).score_samples(P) and the FIRST index of its maximum
+//                                                                            (plot_locator.py:26-37, scripts/plot_locator.R:57-113)
+// score_i = log sum_j exp(-|p_i - p_j|^2 / (2 h^2)) + const: the j = i term is exp(0), so the log-sum-exp needs no shift.
+// One workgroup per sample, float64 throughout (map units): the points sit in LDS (up to KDE_LDS_POINTS; beyond that they are
+// read through L1), thread t scores points t, t + 256, ... by a j-ordered sum - a fixed order, so the result does not depend on
+// the launch - and the workgroup reduces (score, index) with "larger score, then smaller index".  A sample with a non-finite
+// coordinate has no density estimate (sklearn raises; the reference then reports the mean): peak index -1, peak = centroid.
+constexpr int KDE_LDS_POINTS = 4096;          // 64 KB of (x, y) doubles
+
+__global__ __launch_bounds__(256) void kde_peak_kernel(const double* __restrict__ xy, const int64_t* __restrict__ offsets,
+                                                       double inv_2h2, int32_t* __restrict__ peak_index,
+                                                       double* __restrict__ out) {
+    __shared__ double pts[2 * KDE_LDS_POINTS];
+    __shared__ double r_score[256];
+    __shared__ int r_idx[256];
+    __shared__ double r_sx[256], r_sy[256];
+    __shared__ int r_bad[256];
+    const int s = blockIdx.x, t = threadIdx.x;
+    const int64_t o0 = offsets[s];
+    const int n = (int)(offsets[s + 1] - o0);
+    const double* p = xy + 2 * o0;
+    const bool in_lds = n <= KDE_LDS_POINTS;
+    double sx = 0.0, sy = 0.0;
+    int bad = 0;
+    for (int i = t; i < n; i += 256) {
+        const double x = p[2 * i], y = p[2 * i + 1];
+        if (in_lds) { pts[2 * i] = x; pts[2 * i + 1] = y; }
+        sx += x; sy += y;
+        bad |= !(isfinite(x) && isfinite(y));
+    }
+    r_sx[t] = sx; r_sy[t] = sy; r_bad[t] = bad;
+    __syncthreads();
+    const double* q = in_lds ? pts : p;
+    double best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
+        const double xi = q[2 * i], yi = q[2 * i + 1];
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double dx = xi - q[2 * j], dy = yi - q[2 * j + 1];
+            acc += exp(-(dx * dx + dy * dy) * inv_2h2);
+        }
+        const double sc = log(acc);
+        if (sc > best) { best = sc; best_i = i; }          // ascending i: a tie keeps the earlier point
+    }
+    r_score[t] = best; r_idx[t] = best_i;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            r_sx[t] += r_sx[t + w]; r_sy[t] += r_sy[t + w]; r_bad[t] |= r_bad[t + w];
+            const double a = r_score[t], b = r_score[t + w];
+            if (b > a || (b == a && r_idx[t + w] < r_idx[t])) { r_score[t] = b; r_idx[t] = r_idx[t + w]; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double gx = n ? r_sx[0] / (double)n : NAN, gy = n ? r_sy[0] / (double)n : NAN;
+        const bool ok = n > 0 && !r_bad[0] && r_idx[0] != 0x7fffffff;
+        const int pi = ok ? r_idx[0] : -1;
+        peak_index[s] = pi;
+        out[4 * s + 0] = ok ? p[2 * pi] : gx;
+        out[4 * s + 1] = ok ? p[2 * pi + 1] : gy;
+        out[4 * s + 2] = gx;
+        out[4 * s + 3] = gy;
+    }
+}
+
+extern "C" int loc_kde_peak_batch(const double* xy, const int64_t* offsets, int n_samples, double bandwidth,
+                                  int32_t* peak_index, double* out, void* stream) {
+    if (n_samples < 0 || !(bandwidth > 0.0) || (n_samples > 0 && (!xy || !offsets || !peak_index || !out))) {
+        loc_set_error("loc_kde_peak_batch: n_samples=%d bandwidth=%g (needs n_samples >= 0, bandwidth > 0, non-null buffers)",
+                      n_samples, bandwidth);
+        return -1;
+    }
+    if (n_samples == 0) return 0;
+    hipLaunchKernelGGL(kde_peak_kernel, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, xy, offsets,
+                       1.0 / (2.0 * bandwidth * bandwidth), peak_index, out);
+    LOC_CHECK_LAUNCH();
+    return 0;
+}

@@ -407,7 +407,9 @@ def train_network(model, traingen, testgen, trainlocs, testlocs, callbacks, boot
                       lr_factor=reducelr["factor"], use_graph=use_graph, verbose=args.keras_verbose,
                       chain=False if getattr(args, "no_chain", False) else None)
     if args.keep_weights:
-        save_weights(checkpointer["filepath"], model.weights_dict())
+        w = model.weights_dict()                     # device read-back: under the lock
+        with _host_io():
+            save_weights(checkpointer["filepath"], w)
     print("run time " + str((time.time() - start) / 60) + " minutes")
     return history, model
 
@@ -442,19 +444,21 @@ def predict_locs(model, predgen, sdlong, meanlong, sdlat, meanlat, testlocs, pre
     import pandas as pd
     if verbose:
         print("predicting locations...")
-    xy = _to_map_units(model.predict(predgen), sdlong, meanlong, sdlat, meanlat)
-    write_predlocs(_predlocs_path(boot), xy, np.asarray(samples)[pred] if len(pred) else [])
-
-    truth = _to_map_units(testlocs, sdlong, meanlong, sdlat, meanlat)
-    fitted = _to_map_units(model.predict(testgen), sdlong, meanlong, sdlat, meanlat)
-    dists = np.sqrt(((fitted - truth) ** 2).sum(axis=1)).tolist()
-    if verbose:
-        r2 = [np.corrcoef(fitted[:, a], truth[:, a])[0][1] ** 2 for a in (0, 1)]
-        print(f"R2(x)={r2[0]}\nR2(y)={r2[1]}\nmean validation error {np.mean(dists)}\n"
-              f"median validation error {np.median(dists)}\n")
-    if len(history.history.get("loss", [])):
-        table = pd.DataFrame(history.history)
-        _write_atomic(_out() + "_history.txt", lambda fh: table.to_csv(fh, sep="\t", index=False))
+    # the two device passes first (under the device lock when fits share a process), then the host work without it
+    z_pred, z_val = model.predict(predgen), model.predict(testgen)
+    with _host_io():
+        xy = _to_map_units(z_pred, sdlong, meanlong, sdlat, meanlat)
+        write_predlocs(_predlocs_path(boot), xy, np.asarray(samples)[pred] if len(pred) else [])
+        truth = _to_map_units(testlocs, sdlong, meanlong, sdlat, meanlat)
+        fitted = _to_map_units(z_val, sdlong, meanlong, sdlat, meanlat)
+        dists = np.sqrt(((fitted - truth) ** 2).sum(axis=1)).tolist()
+        if verbose:
+            r2 = [np.corrcoef(fitted[:, a], truth[:, a])[0][1] ** 2 for a in (0, 1)]
+            print(f"R2(x)={r2[0]}\nR2(y)={r2[1]}\nmean validation error {np.mean(dists)}\n"
+                  f"median validation error {np.median(dists)}\n")
+        if len(history.history.get("loss", [])):
+            table = pd.DataFrame(history.history)
+            _write_atomic(_out() + "_history.txt", lambda fh: table.to_csv(fh, sep="\t", index=False))
     return dists
 
 
@@ -490,15 +494,54 @@ _FIT_SLOTS = {}
 _FIT_SLOTS_LOCK = __import__("threading").Lock()
 
 
-def _fit_slots(device, K):
-    """Semaphore that admits the concurrent fits of this process on `device` (created at the first unit, from its SNP count)."""
-    import threading
+class _FitBudget:
+    """Admission of the concurrent fits of this process on one device, sized PER UNIT: the device has AUTO_FITS_MAX * 2
+    credits; under --fits_per_gpu 0 a fit of up to AUTO_FITS_SNPS SNPs takes 2 of them (three such fits at a time) and a
+    larger one 3 (two at a time; one large beside one small), so a --windows run whose windows differ in size admits each
+    window by its own SNP count - not by the first window's.  An explicit --fits_per_gpu n admits n fits whatever their
+    size.  The flag comes from the unit's own args (in a worker process the module-global `args` is still None when the
+    first unit asks)."""
+
+    TOTAL = 2 * AUTO_FITS_MAX
+
+    def __init__(self):
+        import threading
+        self._cv = threading.Condition()
+        self._used = 0          # credits out under the automatic rule
+        self._fits = 0          # fits admitted right now (any rule)
+
+    def cost(self, K, a):
+        n = int(getattr(a, "fits_per_gpu", 0) or 0)
+        if n > 0:
+            return 0, max(1, n)                             # (credits, cap on concurrent fits)
+        return (2 if K <= AUTO_FITS_SNPS else 3), AUTO_FITS_MAX
+
+    def acquire(self, K, a):
+        c, cap = self.cost(K, a)
+        with self._cv:
+            # (a lone fit is always admitted: credits can never deadlock)
+            while self._fits > 0 and (self._fits >= cap or self._used + c > self.TOTAL):
+                self._cv.wait()
+            self._fits += 1
+            self._used += c
+        return c
+
+    def release(self, c):
+        with self._cv:
+            self._fits -= 1
+            self._used -= c
+            self._cv.notify_all()
+
+    def admitted(self):
+        with self._cv:
+            return self._fits
+
+
+def _fit_slots(device):
+    """The admission budget of this process's fits on `device` (created at the first unit)."""
     with _FIT_SLOTS_LOCK:
         if device not in _FIT_SLOTS:
-            n = int(getattr(args, "fits_per_gpu", 0) or 0)
-            if n <= 0:
-                n = AUTO_FITS_MAX if K <= AUTO_FITS_SNPS else 2
-            _FIT_SLOTS[device] = threading.BoundedSemaphore(max(1, n))
+            _FIT_SLOTS[device] = _FitBudget()
         return _FIT_SLOTS[device]
 
 
@@ -517,17 +560,40 @@ def _snps_hint(unit):
 def _fit_unit(unit, device="cuda:0"):
     """_fit_unit_body under the process-wide device lock (train.DEVICE_LOCK): when several fits share a process, one thread
     and stream each, everything a fit does on the device outside its epoch loop - upload, net construction, read-backs,
-    predict, and the destruction of its graphs / events / buffers when the body returns - is kept apart from a sibling's
-    HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run).  Before that the unit waits for one of
-    the process's fit slots (_fit_slots: --fits_per_gpu, or 3 / 2 by SNP count) - without holding the lock."""
+    predict launches, and the destruction of its graphs / events / buffers when the body returns OR RAISES - is kept apart
+    from a sibling's HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run), and so does the
+    unit's pure host work (output files, plots: _host_io).  Before that the unit waits for admission (_FitBudget:
+    --fits_per_gpu, or 3 / 2 at a time by the unit's own SNP count) - without holding the lock - and only then reports
+    ("start", index) to the pool through unit["on_admitted"], so --unit_timeout times the fit, not the wait for a sibling."""
+    import traceback
     from .train import DEVICE_LOCK
-    slots = _fit_slots(device, _snps_hint(unit))
-    slots.acquire()
+    budget = _fit_slots(device)
+    credits = budget.acquire(_snps_hint(unit), unit.get("args"))
     try:
+        admitted = unit.pop("on_admitted", None) if isinstance(unit, dict) else None
+        if admitted is not None:
+            admitted()
         with DEVICE_LOCK:
-            return _fit_unit_body(unit, device)
+            try:
+                return _fit_unit_body(unit, device)
+            except Exception as e:                      # noqa: BLE001 - becomes the unit's error record (as replicates._run_one's)
+                # The traceback's frames hold the model, its graphs, events and device buffers: they must go away HERE,
+                # under the lock, not later in a handler that runs while a sibling has a capture open.
+                rec = {"name": unit.get("name", "?"), "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
+                traceback.clear_frames(e.__traceback__)
+                del e
+                return rec
     finally:
-        slots.release()
+        budget.release(credits)
+
+
+_fit_unit.reports_admission = True      # replicates._worker: this fit function sends the unit's ("start", i) itself
+
+
+def _host_io():
+    """Context for a fit's pure host work (files, plots): the device lock is dropped for its duration."""
+    from .train import DEVICE_LOCK
+    return DEVICE_LOCK.released()
 
 
 def _fit_unit_body(unit, device="cuda:0"):
@@ -542,7 +608,8 @@ def _fit_unit_body(unit, device="cuda:0"):
     t_unit = time.time()
     phases = {}
     if "window" in unit and "gt_pin" not in unit:
-        _load_window(unit)          # a no-op when the worker's loader thread has already done it (host_prepare)
+        with _host_io():
+            _load_window(unit)      # a no-op when the worker's loader thread has already done it (host_prepare)
     phases["load"] = time.time() - t_unit
     X = None
     if "gt_pin" in unit:

@@ -74,10 +74,10 @@ def _attach(small, descs):
 
 
 # Fit threads of THIS process (set by the worker / the in-process path before the first fit starts).  Fits that share a
-# process do not capture HIP graphs: capture is process-sensitive on this platform even in thread-local mode - another
-# thread's device-wide wait, or a garbage-collection pass that frees a graph or an event while a capture is open, aborts
-# the process (observed: `Fatal Python error: Aborted` in a 2-replicate --bootstrap, tests/test_gpu_cli.py).  With the
-# callbacks on the device and epochs enqueued ahead, an eagerly launched epoch costs host time, not GPU time.
+# process capture their HIP graphs under train.DEVICE_LOCK (round 5): capture is process-sensitive on this platform even in
+# thread-local mode - another thread's device-wide wait, or a graph / event destroyed while a capture is open, aborts the
+# process - so everything a fit does on the device outside its epoch loop holds that lock.  locator.train_network reads this
+# count to decide whether capture pays at the fit's SNP count (GRAPH_MAX_SNPS_IN_FIT_THREADS).
 _FIT_THREADS = 1
 
 
@@ -188,9 +188,24 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_thread
                 todo.put(item)                               # the siblings see it too
                 return
             idx, unit, err, t_host = item
-            send(("start", idx))
+            # ("start", i) opens the unit's --unit_timeout clock in the parent.  A fit function that queues its units for
+            # admission inside the process (locator._fit_unit: fits_per_gpu / SNP-count budget) sends it itself through
+            # unit["on_admitted"] once the unit is admitted - the wait for a sibling's whole fit is not the unit's time;
+            # any other fit function starts now.  Sent exactly once either way, before ("done", r).
+            started = []
+
+            def admitted(idx=idx, started=started):
+                if not started:
+                    started.append(1)
+                    send(("start", idx))
+
+            if getattr(fit_fn, "reports_admission", False) and err is None and isinstance(unit, dict):
+                unit = dict(unit, on_admitted=admitted)
+            else:
+                admitted()
             t1 = time.time()
             r = err if err is not None else _run_on_own_stream(fit_fn, unit, box["shared"], args, device, prepare)
+            admitted()
             r["unit_index"], r["gpu"] = idx, gpu
             r["host_prepare_seconds"], r["worker_seconds"] = t_host, time.time() - t1
             send(("done", r))
@@ -237,7 +252,8 @@ class ReplicatePool:
     isolate       True: even a single worker is a separate process (crash isolation: a HIP abort in a fit costs that worker,
                   its units are retried on a fresh one); None = only when unit_timeout > 0 (a hung fit can be killed only
                   as a process); False = a single worker runs inside the calling process.
-    unit_timeout  seconds a unit may spend in a worker after it reported ("start", i), or an otherwise idle worker may
+    unit_timeout  seconds a unit may spend in a worker after it reported ("start", i) - sent when the fit is ADMITTED, so time
+                  queued behind a sibling fit of the same worker does not count -, or an otherwise idle worker may
                   spend on a unit's host work before that report; a worker that exceeds it is
                   killed (its exact process, never a pattern), the unit becomes an error record and a FRESH process
                   takes the slot - a hung (not dead) worker no longer blocks the run.  0 = no limit.

@@ -16,6 +16,11 @@ and, when the sample file has known coordinates, the error of both summaries.  O
 
 Deviation: the reference's file loop reads `files[i]` for i in range(len(files[1:])) (plot_locator.py:67-70),
 i.e. the first file twice and never the last; here every file is read once.
+
+Every sample's kernel-density peak and centroid come from ONE launch of the library's `loc_kde_peak_batch` (one workgroup
+per sample, float64, include/locator_hip.h; `device_summaries`).  There is no silent fallback: without a GPU (or without the
+library) the run stops and says so.  `--host` asks for the NumPy form explicitly (`kde_peak` / `centroid` below) - a
+post-processing convenience for a machine without a GPU, and what tests/test_gpu_summarize.py checks the kernel against.
 """
 from __future__ import annotations
 
@@ -42,7 +47,30 @@ def centroid(x, y):
     return float(np.sum(x) / len(x)), float(np.sum(y) / len(y))
 
 
-def summarize(indir, sample_data=None, out=None, bandwidth=0.2, silence=False):
+def device_summaries(groups, bandwidth=0.2, device="cuda:0"):
+    """[(x array, y array), ...] -> (peak index, [kd_x, kd_y, gc_x, gc_y]) per sample from one loc_kde_peak_batch launch.
+    peak index -1 = no density estimate (non-finite coordinate / no points): kd = centroid, as kde_peak reports it."""
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    n = len(groups)
+    counts = np.array([len(x) for x, _ in groups], dtype=np.int64)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    xy = np.empty((int(offsets[-1]), 2), dtype=np.float64)
+    for (x, y), o0, o1 in zip(groups, offsets[:-1], offsets[1:]):
+        xy[o0:o1, 0], xy[o0:o1, 1] = x, y
+    with torch.cuda.device(device):
+        d_xy = torch.from_numpy(xy).to(device)
+        d_off = torch.from_numpy(offsets).to(device)
+        d_idx = torch.empty(n, dtype=torch.int32, device=device)
+        d_out = torch.empty((n, 4), dtype=torch.float64, device=device)
+        _lib.check(lib.loc_kde_peak_batch(d_xy.data_ptr(), d_off.data_ptr(), n, float(bandwidth), d_idx.data_ptr(),
+                                          d_out.data_ptr(), torch.cuda.current_stream().cuda_stream), "loc_kde_peak_batch")
+        return d_idx.cpu().numpy(), d_out.cpu().numpy()
+
+
+def summarize(indir, sample_data=None, out=None, bandwidth=0.2, silence=False, host=False):
     import pandas as pd
     files = sorted(f for f in os.listdir(indir) if "predlocs" in f)
     if not files:
@@ -53,9 +81,20 @@ def summarize(indir, sample_data=None, out=None, bandwidth=0.2, silence=False):
     if sample_data is not None:
         truth = pd.read_csv(sample_data, sep="\t").set_index("sampleID")
     rows = []
-    for sid, grp in aeg.groupby("sampleID", sort=False):
-        kx, ky = kde_peak(grp["xpred"].to_numpy(), grp["ypred"].to_numpy(), bandwidth)
-        gx, gy = centroid(grp["xpred"].to_numpy(), grp["ypred"].to_numpy())
+    groups = [(sid, grp["xpred"].to_numpy(), grp["ypred"].to_numpy()) for sid, grp in aeg.groupby("sampleID", sort=False)]
+    dev = None
+    if not host:
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("locator_amd.summarize: no GPU visible (the summaries are one loc_kde_peak_batch launch); "
+                             "pass --host for the NumPy form")
+        dev = device_summaries([(x, y) for _, x, y in groups], bandwidth)[1]
+    for i, (sid, xs, ys) in enumerate(groups):
+        if dev is not None:
+            kx, ky, gx, gy = (float(v) for v in dev[i])
+        else:
+            kx, ky = kde_peak(xs, ys, bandwidth)
+            gx, gy = centroid(xs, ys)
         tx = ty = np.nan
         if truth is not None and sid in truth.index:
             tx, ty = float(truth.loc[sid, "x"]), float(truth.loc[sid, "y"])
@@ -81,8 +120,9 @@ def main(argv=None):
     ap.add_argument("--out", required=True, help="output stem ({out}_centroids.txt)")
     ap.add_argument("--bandwidth", type=float, default=0.2)
     ap.add_argument("--silence", action="store_true")
+    ap.add_argument("--host", action="store_true", help="NumPy summaries even when a GPU is visible")
     a = ap.parse_args(argv)
-    summarize(a.infile, a.sample_data, a.out, a.bandwidth, a.silence)
+    summarize(a.infile, a.sample_data, a.out, a.bandwidth, a.silence, host=a.host)
     return 0
 
 

@@ -19,10 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def _kernels(source, pattern):
-    """{mangled name: assembly lines} of the kernels of locator_amd/csrc/<source> whose name matches `pattern`."""
+def _kernels(source, pattern, defines=()):
+    """{mangled name: assembly lines} of the kernels of locator_amd/csrc/<source> whose name matches `pattern` (defines: extra
+    -D switches, for checking a measurement build)."""
     out = os.path.join(tempfile.mkdtemp(prefix="asm_check_"), "k.s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                           *[f"-D{d}" for d in defines],
                            os.path.join(ROOT, "locator_amd", "csrc", source), "-o", out], stderr=subprocess.DEVNULL)
     text = open(out).read()
     shutil.rmtree(os.path.dirname(out), ignore_errors=True)
@@ -35,8 +37,8 @@ def _kernels(source, pattern):
     return res
 
 
-def _kernel_asm(nht=8, rb=1):
-    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13ELi%dELi%dEE" % (nht, rb))
+def _kernel_asm(nht=8, rb=1, defines=()):
+    ks = _kernels("l1_chain.hip", r"^_Z24l1_bwd_adam_chain_kernelILi13ELi%dELi%dEE" % (nht, rb), defines)
     assert len(ks) == 1, f"kernel instantiation <13, {nht}, {rb}> not found in the assembly"
     return next(iter(ks.values()))
 

@@ -322,7 +322,10 @@ def test_summarize_centroid_and_kernel_peak(tmp_path):
                                                                           index=False)
     sd = tmp_path / "samples.txt"
     pd.DataFrame({"sampleID": ids, "x": truth[:, 0], "y": truth[:, 1]}).to_csv(sd, sep="\t", index=False)
-    bp = S.summarize(str(tmp_path), str(sd), str(tmp_path / "out"), silence=True)
+    bp = S.summarize(str(tmp_path), str(sd), str(tmp_path / "out"), silence=True, host=True)
+    if not __import__("torch").cuda.is_available():      # the default is the device launch: no silent NumPy fallback
+        with pytest.raises(SystemExit, match="no GPU visible"):
+            S.summarize(str(tmp_path), str(sd), str(tmp_path / "out2"), silence=True)
     assert list(bp.columns) == ["sampleID", "x", "y", "kd_x", "kd_y", "gc_x", "gc_y"] and len(bp) == 5
     P = np.array(preds)                        # (12, 5, 2)
     assert np.allclose(bp[["gc_x", "gc_y"]].to_numpy(), P.mean(0))
@@ -439,24 +442,84 @@ def test_device_lock_is_reentrant_per_thread_and_released_drops_the_whole_hold()
     assert got == [1]
 
 
-def test_fit_slots_admit_three_small_fits_or_two_large_ones_unless_the_flag_says_otherwise(monkeypatch):
+def test_fit_budget_admits_by_each_units_own_snp_count_and_reads_the_flag_from_the_unit(monkeypatch):
     """--fits_per_gpu 0 (the default since round 5): the pool starts three fit threads per GPU and locator._fit_unit admits
-    as many units at a time as their SNP count asks for - 3 up to 70,000 SNPs, 2 above (bench.py --replicates-per-gpu sweep:
-    903k against 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k against 226k at 100,000); an explicit flag wins."""
+    as many units at a time as their SNP counts ask for - 3 up to 70,000 SNPs, 2 above (bench.py --replicates-per-gpu sweep:
+    903k against 711k samples/s for 3 / 2 fits at 5,830 SNPs, 221k against 226k at 100,000), one large beside one small;
+    an explicit flag wins.  Round 6: the rule is applied PER UNIT (a small first window no longer decides for
+    the 150k-variant windows behind it) and the flag is read from the unit's own args - in a spawned worker the module
+    global is still None when the first unit asks, so --fits_per_gpu 4 used to admit 3."""
     class A:
         fits_per_gpu = 0
-    monkeypatch.setattr(L, "args", A, raising=False)
+    monkeypatch.setattr(L, "args", None, raising=False)              # what a fresh worker process has
     assert L._snps_hint({"window": (100, 1250)}) == 1150 and L._snps_hint({"gt_shape": (150016, 765, 2)}) == 150016
     assert L._snps_hint({"traingen": np.zeros((5, 77), np.uint8)}) == 77 and L._snps_hint({}) == 0
-    for K, flag, want in ((5830, 0, 3), (70_000, 0, 3), (70_001, 0, 2), (560_000, 0, 2), (5830, 1, 1), (560_000, 4, 4)):
+
+    def admitted_without_blocking(budget, Ks, a):
+        import threading
+        got = []
+        for K in Ks:
+            th = threading.Thread(target=lambda K=K: got.append(budget.acquire(K, a)), daemon=True)
+            th.start()
+            th.join(0.3)
+        return len(got)
+
+    for Ks, flag, want in (([5830] * 5, 0, 3), ([70_000] * 5, 0, 3), ([70_001] * 5, 0, 2), ([560_000] * 4, 0, 2),
+                           ([150_000, 1150, 1150], 0, 2), ([1150, 1150, 150_000], 0, 2), ([1150, 150_000, 150_000], 0, 2),
+                           ([5830] * 3, 1, 1), ([560_000] * 6, 4, 4)):
         monkeypatch.setattr(L, "_FIT_SLOTS", {})
         A.fits_per_gpu = flag
-        sem = L._fit_slots("cuda:0", K)
-        got = 0
-        while sem.acquire(blocking=False):
-            got += 1
-        assert got == want, (K, flag, got)
-        assert L._fit_slots("cuda:0", 1) is sem                      # decided once per process and device
+        budget = L._fit_slots("cuda:0")
+        assert admitted_without_blocking(budget, Ks, A) == want, (Ks, flag)
+        assert L._fit_slots("cuda:0") is budget                      # one budget per process and device
+    # release lets the queued one in, and a lone fit is always admitted whatever its size
+    monkeypatch.setattr(L, "_FIT_SLOTS", {})
+    A.fits_per_gpu = 0
+    budget = L._fit_slots("cuda:1")
+    c1, c2 = budget.acquire(10 ** 6, A), budget.acquire(10 ** 6, A)
+    assert budget.admitted() == 2
+    import threading
+    late = []
+    th = threading.Thread(target=lambda: late.append(budget.acquire(10 ** 6, A)), daemon=True)
+    th.start()
+    th.join(0.2)
+    assert not late
+    budget.release(c1)
+    th.join(2)
+    assert late == [3] and budget.admitted() == 2
+    budget.release(c2), budget.release(late[0])
+    assert budget.admitted() == 0
+
+
+def _queued_fit(unit, device="cpu"):
+    """A fit function with in-process admission like locator._fit_unit: ONE fit at a time per process however many fit
+    threads the worker has; ("start", i) is reported through unit["on_admitted"] when the unit is admitted."""
+    import threading
+    import time
+    gate = _queued_fit.__dict__.setdefault("gate", threading.Lock())
+    with gate:
+        unit.pop("on_admitted")()
+        time.sleep(0.8)
+    return {"name": unit["name"], "value": unit["replicate"], "seconds": 0.8}
+
+
+_queued_fit.reports_admission = True
+
+
+def test_unit_timeout_counts_from_admission_not_from_the_wait_for_a_sibling_fit():
+    """with three fit threads and fewer admission slots a unit may wait for a sibling's whole fit inside the
+    worker.  Its --unit_timeout clock starts when the fit function reports admission (unit["on_admitted"]), so a healthy
+    run with fit time < timeout < 2 x fit time completes; it used to lose the worker and two healthy fits."""
+    units = [dict(name=f"q{i}", replicate=i) for i in range(6)]
+    logs = []
+    res = R.run_units(units, _Args(), _queued_fit, n_gpus=1, fits_per_gpu=3, procs_per_gpu=1, log=logs.append, poll_s=0.05,
+                      unit_timeout=1.3)
+    assert [r.get("value") for r in res] == list(range(6)), (res, logs)
+    assert not any("exceeded --unit_timeout" in str(l) for l in logs)
+    # a fit function that does not report admission itself is started by the worker, exactly once
+    res = R.run_units(_units(3), _Args(), _fake_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=1, shared={"shared_bias": 1.0},
+                      log=logs.append, poll_s=0.05, isolate=True)
+    assert all("error" not in r for r in res)
 
 
 def test_bench_launches_its_own_ranks_without_torchrun(repo_root):
