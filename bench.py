@@ -118,13 +118,13 @@ def l1_gemm_summary(net, n_matrix, iters=10):
 
     import torch
     from locator_amd import _lib
-    from tools.l1_gemm_sweep import _time_graphed, distinct_rows
+    from tools.l1_gemm_sweep import REPLAYS, _time_graphed, _time_graphed_ab, distinct_rows
     lib, d, lay = net.lib, net.d, net.lay
     P, dev = net.params.data_ptr(), net.params.device
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = net.quant_guard()
     digits = int(g[2])
-    out = {"mode": "int8x%d" % digits if digits > 0 else "bf16x3", "peak_tflops": BF16_PEAK_TFLOPS,
+    out = {"mode": "int8x%d" % digits if digits > 0 else "bf16x3", "peak_tflops": BF16_PEAK_TFLOPS, "timing": "median of %d graph replays" % REPLAYS,
            "guard_median": round(g[0], 1), "guard_max": round(g[1], 1)}
     if digits <= 0 or not lib.loc_l1_gemm_i8_supported(d.Hp, digits):
         return out
@@ -147,17 +147,25 @@ def l1_gemm_summary(net, n_matrix, iters=10):
         run = lambda: _lib.check(lib.loc_l1_forward_gemm_i8(X.data_ptr(), X.stride(0), rows.data_ptr(), n_rows, C.byref(d),
                                                             image.data_ptr(), digits, 2, P + 4 * lay.b1, partial.data_ptr(),
                                                             partial.numel(), a1.data_ptr(), 0, None, st()))
-        us = _time_graphed(run, iters)
-        r = {"us": round(us, 1), "frac": frac(fl, us), "incl_prep": frac(fl, us + us_prep)}
-        if packed:
+        if not packed:
+            us = _time_graphed(run, iters)
+            sp = _time_graphed.last
+            return {"us": round(us, 1), "min_max": [round(sp["min"], 1), round(sp["max"], 1)], "frac": frac(fl, us),
+                    "incl_prep": frac(fl, us + us_prep)}
+        else:
             X2 = torch.zeros((X.shape[0], d.Kp // 4), dtype=torch.uint8, device=dev)
             _lib.check(lib.loc_pack_genotypes_2bit(X.data_ptr(), X.stride(0), X.shape[0], d.Kp, X2.data_ptr(), X2.stride(0), st()))
             runp = lambda: _lib.check(lib.loc_l1_forward_gemm_i8_packed(X2.data_ptr(), X2.stride(0), rows.data_ptr(), n_rows,
                                                                         C.byref(d), image.data_ptr(), digits, P + 4 * lay.b1,
                                                                         partial.data_ptr(), partial.numel(), a1.data_ptr(), 0,
                                                                         None, st()))
-            usp = _time_graphed(runp, iters)
-            r["packed"] = {"us": round(usp, 1), "frac": frac(fl, usp), "incl_prep": frac(fl, usp + us_prep)}
+            # bytes and packed interleaved replay by replay (same clock state): medians of REPLAYS each
+            sb, sp = _time_graphed_ab([run, runp], iters)
+            us, usp = sb["median"], sp["median"]
+            r = {"us": round(us, 1), "min_max": [round(sb["min"], 1), round(sb["max"], 1)], "frac": frac(fl, us),
+                 "incl_prep": frac(fl, us + us_prep)}
+            r["packed"] = {"us": round(usp, 1), "min_max": [round(sp["min"], 1), round(sp["max"], 1)], "frac": frac(fl, usp),
+                           "incl_prep": frac(fl, usp + us_prep)}
         return r
 
     out["rows_%d" % n_matrix] = shape(net.X, n_matrix, n_matrix, False)

@@ -94,6 +94,9 @@ def build_parser():
     p.add_argument("--unit_timeout", default=0, type=float,
                    help="seconds one --windows / --bootstrap replicate may take inside a worker before that worker is "
                         "killed and replaced and the replicate reported as failed (default 0: no limit)")
+    p.add_argument("--worker_start", default="forkserver", choices=("forkserver", "spawn"),
+                   help="how --windows / --bootstrap worker processes start: forked from a server that imported torch once and "
+                        "never touches a GPU (default: a worker costs a fork + one device context), or a fresh interpreter each")
     p.add_argument("--in_process", default=False, action="store_true",
                    help="--windows / --bootstrap on ONE GPU: run the replicate fits on threads of this process instead of a "
                         "worker process (saves the worker's start-up; no crash isolation, and --unit_timeout then still "
@@ -868,8 +871,14 @@ def _unit_count_bound():
 
 def main(argv=None):
     t_program = time.time()
-    _setup(argv)
     from . import replicates
+    raw = sys.argv[1:] if argv is None else list(argv)
+    if (("--windows" in raw or "--bootstrap" in raw) and "--in_process" not in raw
+            and not any(a == "spawn" or a == "--worker_start=spawn" for a in raw)):
+        # replicate runs: the fork server starts FIRST - its `import torch` overlaps this process's own parsing, imports and
+        # prologue, and every worker is then a fork + one device context (replicates.warm_start)
+        replicates.warm_start("forkserver")
+    _setup(argv)
 
     pool = None
     if args.windows or args.bootstrap:

@@ -115,7 +115,7 @@ def _run_on_own_stream(fit_fn, unit, shared, args, device, prepare):
                 "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
 
 
-def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_threads=1):
+def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_threads=1, env=None):
     """Worker process on its own duplex pipe (no queue or lock is shared between workers, so one that is killed
     cannot wedge the others).  Start-up (import torch, device context, HIP library) happens right away - the parent
     spawns the pool BEFORE its own prologue so that the two overlap.  Messages in: ("shared", small, descs) once,
@@ -126,20 +126,24 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_thread
     import threading
     import time
     t0 = time.time()
+    numa = None
     try:
+        _bind_worker_to_gpu(gpu, env)                           # HIP_VISIBLE_DEVICES, before this process's first HIP call
         import torch
         if torch.cuda.is_available():
-            torch.cuda.set_device(gpu)
-            device = f"cuda:{gpu}"
+            device = "cuda:0"                                   # the only device this process sees
+            torch.cuda.set_device(0)
             torch.zeros(1, device=device)                       # device context now, not inside the first fit
             from . import _lib
             _lib.load()
+            numa = _bind_worker_to_numa_node(device)
         else:               # scheduler tests on CPU; a real fit_fn raises on this device (no CPU fallback)
             device = "cpu"
     except Exception as e:                                   # noqa: BLE001 - the parent turns it into error records
         conn.send(("dead", f"worker start-up failed: {type(e).__name__}: {e}"))
         return
-    conn.send(("ready", {"startup_seconds": time.time() - t0, "spawn_seconds": t0 - t_parent, "ready_at": time.time()}))
+    conn.send(("ready", {"startup_seconds": time.time() - t0, "spawn_seconds": t0 - t_parent, "ready_at": time.time(),
+                         "cpu_affinity": numa}))
     todo = queue.Queue()
     box = {"shared": {}, "keep": []}
 
@@ -229,8 +233,98 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_thread
 
 
 def visible_gpus():
+    """GPUs this process may use, counted WITHOUT importing torch or touching the GPU when the kernel driver's topology is
+    readable (/sys/class/kfd: a node with simd_count > 0 is a GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow it): the
+    parent of a replicate run starts its workers first thing, and `import torch` alone is a second of that critical path."""
+    import glob
+    import os
+    try:
+        n = 0
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        if n > 0:
+            for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+                v = os.environ.get(var)
+                if v is not None:
+                    n = min(n, len([t for t in v.split(",") if t.strip() not in ("", "-1")]))
+            return n
+    except (OSError, ValueError):
+        pass
     import torch
     return torch.cuda.device_count()
+
+
+START_METHOD = "forkserver"       # how worker processes come to be: "forkserver" (default) or "spawn"
+_PRELOAD = ["numpy", "torch", "locator_amd._lib", "locator_amd.net", "locator_amd.train", "locator_amd.replicates",
+            "locator_amd.locator"]
+
+
+def warm_start(method=None):
+    """Start the fork server NOW (first thing in a replicate run, before the parent parses, imports or reads anything): a fresh
+    interpreter that imports torch and this package ONCE - without any GPU call - and from then on forks every worker process on
+    request.  A worker then costs a fork + one HIP context (about 0.3 s) instead of an interpreter start + `import torch`
+    (1.0-1.1 s each, round 5), also when a lost worker is replaced in the middle of a run, and the server's imports overlap the
+    parent's own start-up.  Never forks or execs a process that has touched the GPU: the server never does, and the parent
+    starts it (an exec) before its own first GPU call.  No-op for "spawn"."""
+    import multiprocessing as mp
+    method = method or START_METHOD
+    if method != "forkserver":
+        return None
+    ctx = mp.get_context("forkserver")
+    ctx.set_forkserver_preload(list(_PRELOAD))
+    from multiprocessing import forkserver
+    forkserver.ensure_running()
+    return ctx
+
+
+def _visible_env():
+    """What the parent's environment says about visible devices, to be re-applied inside a worker: a forked worker inherits
+    the FORK SERVER's environment (started before --gpu_number was parsed), not the parent's."""
+    import os
+    return {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+
+
+def _bind_worker_to_gpu(gpu, env=None):
+    """Before the worker's first HIP call: make GPU `gpu` (an index into what the parent sees) the ONLY device this process
+    sees - it is then cuda:0 here.  One process per GPU the ROCm way: no context is ever created on a
+    sibling's device, and a stray `cuda:0` default cannot land on another worker's GPU."""
+    import os
+    for k, v in (env or {}).items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    base = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    ids = [t.strip() for t in base.split(",") if t.strip()] if base else None
+    os.environ["HIP_VISIBLE_DEVICES"] = ids[gpu] if ids and gpu < len(ids) else str(gpu)
+    os.environ.pop("CUDA_VISIBLE_DEVICES", None)            # (HIP honours both; one statement of the truth)
+
+
+def _bind_worker_to_numa_node(device):
+    """Best effort: keep the worker's threads on the CPUs local to its GPU (the PCI device's local_cpulist in sysfs).  Returns a
+    short description for the pool's timeline, or None when the topology does not say."""
+    import os
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        addr = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{addr}/local_cpulist") as fh:
+            text = fh.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        have = os.sched_getaffinity(0)
+        want = cpus & have
+        if want and want != have:
+            os.sched_setaffinity(0, want)
+            return f"{addr}: {len(want)} of {len(have)} CPUs"
+        return f"{addr}: all {len(have)} CPUs local"
+    except Exception:                                        # noqa: BLE001 - affinity is a speed hint
+        return None
 
 
 class ReplicatePool:
@@ -265,13 +359,14 @@ class ReplicatePool:
     two messages requeues the unit the same way."""
 
     def __init__(self, args, fit_fn, n_gpus=None, fits_per_gpu=1, prepare=None, host_prepare=None, log=print,
-                 poll_s=1.0, unit_timeout=0.0, max_workers=None, procs_per_gpu=None, isolate=None):
+                 poll_s=1.0, unit_timeout=0.0, max_workers=None, procs_per_gpu=None, isolate=None, start_method=None):
         """fits_per_gpu concurrent fits per GPU, run by procs_per_gpu worker processes per GPU (None = fits_per_gpu: one fit
         per process, the rounds 1-3 layout) with ceil(fits_per_gpu / procs_per_gpu) fit threads each, every thread on its
         own stream.  max_workers caps the CONCURRENT FITS (= the number of units, usually)."""
         import time
         self.args, self.fit_fn, self.prepare, self.host_prepare = args, fit_fn, prepare, host_prepare
         self.log, self.poll_s, self.unit_timeout = log, poll_s, float(unit_timeout or 0.0)
+        self.start_method = start_method or getattr(args, "worker_start", None) or START_METHOD
         n_vis = visible_gpus()
         self.n_g = max(1, min(n_gpus or n_vis, max(n_vis, 1)))
         fits = max(1, int(fits_per_gpu))
@@ -305,8 +400,12 @@ class ReplicatePool:
             return self
         if self.n <= 1 and not self.isolate:
             return self                     # one process = this one: run() drives the fit threads itself
-        import torch.multiprocessing as mp
-        self.ctx = mp.get_context("spawn")
+        # plain multiprocessing (only NumPy / pickled records cross the pipes): the parent does not import torch to start workers.
+        # "forkserver" (default): the workers are forked from a server that has imported torch and this package once and has
+        # never touched a GPU (warm_start - locator.main calls it first thing, so the imports overlap the parent's start-up);
+        # "spawn": a fresh interpreter per worker (rounds 1-5).
+        import multiprocessing as mp
+        self.ctx = warm_start(self.start_method) or mp.get_context("spawn")
         for w in range(self.n):
             self._start_worker(w % self.n_g)
         return self
@@ -316,7 +415,7 @@ class ReplicatePool:
         a, b = self.ctx.Pipe(duplex=True)
         t = time.time()
         p = self.ctx.Process(target=_worker, args=(gpu, self.fit_fn, self.args, self.prepare, self.host_prepare, b, t,
-                                                   self.threads), daemon=True)
+                                                   self.threads, _visible_env()), daemon=True)
         p.start()
         b.close()                           # the parent keeps only its own end: EOF then means "the worker is gone"
         self.workers[a] = {"p": p, "gpu": gpu, "inflight": [], "active": {}, "ready": False,

@@ -23,9 +23,12 @@ sys.path.insert(0, ROOT)
 BF16_PEAK_TFLOPS = 2500.0    # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
-def _time_graphed(fn, iters):
-    """Mean microseconds of fn() (which enqueues on the current stream), replayed from a captured HIP graph so host
-    launch overhead does not pad kernel time."""
+REPLAYS = 9     # timed replays per figure: every quoted time is the MEDIAN of this many (one replay of a kernel
+#                 whose clock sags under matrix load is a sample, not a measurement)
+
+
+def _capture(fn, iters):
+    """A HIP graph of `iters` back-to-back fn() (which enqueues on the current stream) and the stream it replays on."""
     import torch
     for _ in range(3):
         fn()
@@ -37,15 +40,52 @@ def _time_graphed(fn, iters):
         with torch.cuda.graph(g, stream=s):
             for _ in range(iters):
                 fn()
-        g.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g.replay()                           # warm replay, untimed
         s.synchronize()
+    return g, s
+
+
+def _replay_us(g, s, iters):
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s):
         e0.record(s)
         g.replay()
         e1.record(s)
         s.synchronize()
-    torch.cuda.current_stream().wait_stream(s)
     return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def _stats(samples):
+    import statistics
+    return {"median": statistics.median(samples), "min": min(samples), "max": max(samples), "replays": len(samples)}
+
+
+def _time_graphed(fn, iters, replays=REPLAYS):
+    """MEDIAN microseconds of fn() over `replays` timed replays of a captured HIP graph of `iters` back-to-back launches (a graph:
+    host launch overhead does not pad kernel time; the sustained, clocked-down rate).  `_time_graphed.last` keeps
+    {median, min, max, replays} of the call."""
+    import torch
+    g, s = _capture(fn, iters)
+    st = _stats([_replay_us(g, s, iters) for _ in range(max(1, replays))])
+    torch.cuda.current_stream().wait_stream(s)
+    _time_graphed.last = st
+    return st["median"]
+
+
+def _time_graphed_ab(fns, iters, rounds=REPLAYS):
+    """Interleaved A/B(/C...) timing of several variants in ONE process: a graph per variant, `rounds` rounds of one timed replay
+    each in turn (clock state, box and time are shared, so the differences are the variants').  Returns one {median, min, max,
+    replays} per variant."""
+    import torch
+    caps = [_capture(fn, iters) for fn in fns]
+    samples = [[] for _ in fns]
+    for _ in range(max(1, rounds)):
+        for i, (g, s) in enumerate(caps):
+            samples[i].append(_replay_us(g, s, iters))
+    for _, s in caps:
+        torch.cuda.current_stream().wait_stream(s)
+    return [_stats(v) for v in samples]
 
 
 def _time_burst(fn, n=3, idle_s=0.25):
@@ -126,6 +166,7 @@ def l1_gemm_roofline(net, n_matrix, iters=20, x_distinct=None):
             us_prep = _time_graphed(prep, 10)
             us = _time_graphed(run, iters)
             r = rec(us, mfma_equiv, byts)
+            r["us_min_max"] = [round(_time_graphed.last["min"], 1), round(_time_graphed.last["max"], 1)]
             r["us_prep"] = round(us_prep, 1)
             us_b = _time_burst(run)
             r["burst_of_3"] = {"us": round(us_b, 1), "frac_bf16_peak": round(flops / us_b * 1e-6 / BF16_PEAK_TFLOPS, 4)}
