@@ -192,8 +192,10 @@ typedef struct loc_net {
 /* Rows from which the int8 image + GEMM beats the in-loop-conversion bf16x3 kernel including its once-per-call max pass
  * and conversion (K = 100,000, profiles/r03_gemm_bench.json). */
 #define LOC_GEMM_I8_MIN_ROWS(digits) 512
-/* rows per launch from which the int8 GEMM is faster on 2-bit packed genotypes (measured: 1000 rows 4 % slower, 4096 rows
- * 12 % faster when the rows stream from HBM) */
+/* rows per launch from which the int8 GEMM reads the 2-bit packed genotypes WHEN THE CALLER SUPPLIES THEM (loc_net.X2).  Round 6,
+ * medians of interleaved graph replays (profiles/r06_gemm_packed_crossover.jsonl): rows streaming from HBM 2 % faster at 2048
+ * rows, 5-6 % at 3072..8192, 10-12 % at 12,288..16,384; rows repeating a cache-resident matrix 3-6 % SLOWER at every count.
+ * Building X2 costs 21 us per 100 MB, so nothing packs on its own (LocatorNet.auto_pack / --predict_packed are opt-in) */
 #define LOC_GEMM_I8_PACKED_MIN_ROWS 3072
 /* Rows from which image + GEMM beats the in-loop-conversion kernel INCLUDING the once-per-call conversion, measured at
  * K = 100,000 (profiles/r02_bench_default.json: in-loop 0.20 / 0.12 us per row at 3 / 1 pieces; image 51 / 30 us plus

@@ -68,11 +68,6 @@
 #ifndef LOC_CHAIN_EARLY
 #define LOC_CHAIN_EARLY 0
 #endif
-// The next forward of k-tile T inside step T + 1 (width 256): see FWD_LAG in the kernel.  0 = the rounds 3-5 order (the forward
-// right behind its own k-tile's barrier), kept as the A/B twin: make variant F=l1_chain XDEF=-DLOC_CHAIN_FWDLAG=0 TAG=nolag
-#ifndef LOC_CHAIN_FWDLAG
-#define LOC_CHAIN_FWDLAG 0
-#endif
 
 // -DLOC_CHAIN_STAMPS=<workgroup>: a measurement build (tools/probes/chain_stamps.py) in which every wave of one workgroup leaves
 // the cycle counter at eight points of every k-tile iteration (results unchanged)
@@ -153,7 +148,7 @@ constexpr int ch_upw(int nht) { return nht > 8 ? nht / 8 : 1; }      // unit til
 constexpr int ch_smf(int rb) { return CH_SM + 512 * (rb - 1); }       // floats of one k-tile's small operands
 constexpr size_t ch_lds_floats(int nht, int rb = 1) {
     return 32 * rb * (nht * 32 + 1) + 64 * rb + 8 * ch_upw(nht) * 32 * CH_TP + 2 * 8 * 64 + 8 * 64 + 2 * ch_ktw(nht) * ch_smf(rb) +
-           ((nht != 8 || rb > 1) ? nht * 32 : 0) + ((nht == 8 && rb == 1) ? 8 * 64 * 4 : 0);
+           ((nht != 8 || rb > 1) ? nht * 32 : 0);
 }
 
 // The hand-counted wait: at most N vector-memory operations outstanding; the operands tie every register an untracked load
@@ -236,21 +231,9 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     // m, v [64] each, next [mean|var][32]
     float* sm = ssl + 8 * 64;
     float* dzs_l = sm + 2 * KTW * SMF;                          // [Hp] column sums of dZ (unless DZS_REG: see dzs below)
-    // FWD_LAG (width 256): the forward part of k-tile T - 16 dependent fp32 MFMAs per row block, 1024+ matrix-pipe cycles with
-    // nothing of this wave's to run beside them when they sit behind the tile's barrier (cycle stamps, round 6: 3.0-4.0k of a
-    // wave's 17k cycles per iteration) - runs inside step T + 1 instead, ONE MFMA behind each weight's Adam update, where the
-    // 16 x ~12 vector-ALU instructions of the update fill the matrix pipe's shadow.  Same products in the same order into the
-    // same accumulator (k-tiles ascending, SNPs ascending): bit-identical partial sums.  What the deferred forward needs
-    // from its own tile survives by construction: W'(T) transposed in this wave's Tw (rewritten only behind step T + 1's
-    // quarters), (scale' | shift')(T) in this wave's ssw (rewritten behind barrier T + 1), and the next minibatch's genotype
-    // bytes of the tile, which go from the small-operand buffer (refilled by faster waves before step T + 1 ends) into a
-    // per-wave slot here.  The forward of a workgroup's LAST tile runs behind the loop.
-    constexpr bool FWD_LAG = LOC_CHAIN_FWDLAG && KTW == 1 && UPW == 1 && RB == 1;   // (two row blocks: 21 spilled registers - not taken)
-    u32x4* xrl0 = reinterpret_cast<u32x4*>(dzs_l + ((NHT != 8 || RB > 1) ? Hp : 0));   // [8][RB][64] (NHT == 8 only)
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int jl = lane & 31, hi = lane >> 5;
-    u32x4* xrl = xrl0 + w * RB * 64;
     const int ut0 = w % WPS, kq = w / WPS;       // this wave's (first) unit tile, and its k-tile slot inside the super-tile
     const int nkt = Kp / KT, S = (nkt + KTW - 1) / KTW;
     // k-tile of slot `slot` of super-tile T, or -1 (no such super-tile, or past the end of a short last one)
@@ -431,8 +414,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     float pg_acc = 0.f, pb_acc = 0.f;     // this wave's (dgamma | dbeta) partial over the sub-steps of a k-tile
     int stamp_it = 0;                     // (measurement build: iteration number of the stamps)
     (void)stamp_it;
-    bool lag_on = false;                  // FWD_LAG: a k-tile's forward is pending (wave-uniform)
-    (void)xrl;
 
     // Vector-memory operations of one sub-step, in program order (the hand-counted wait depends on it):
     //   12 prefetch loads | wait | 12 stores of this unit | last sub-step of the k-tile: 3 small loads of tile + 2 per role |
@@ -451,7 +432,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         const int ktv = ktile(T, kq);
         // false only for the missing slots of a short last super-tile (wave-uniform); a workgroup that owns whole k-tiles
         // (UPW > 1 implies KTW == 1) has none
-        const bool valid = (UPW > 1 || KTW == 1) ? true : ktv >= 0;     // (a workgroup that owns whole k-tiles is only called with real ones)
+        const bool valid = UPW > 1 || ktv >= 0;
         const int kt = valid ? ktv : 0;
         const int k = kt * KT + jl;
         // this tile's small operands from LDS
@@ -475,29 +456,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         CH_STAMP(0)
         if (!(LOC_CHAIN_EARLY && UPW == 1)) load_unit(ktile(T_pref, kq), ut0 + WPS * ((SUB + 1) % UPW), wn, mn, vn);
         CH_STAMP(1)
-        if constexpr (FWD_LAG && LOC_CHAIN_FWDLAG == 2 && !(LOC_CHAIN_ABLATE & 4)) {
-            // the previous k-tile's forward in the shadow of the wait for this tile's unit (nothing here touches a register
-            // an untracked load may still be writing: LDS reads, vector ALU, MFMAs into facc)
-            if (lag_on) {
-                u32x4 xl[RB];
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) xl[rb] = xrl[rb * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssw + 16 * hi + 4 * j);
-                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(ssw + 32 + 16 * hi + 4 * j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float wt = Tw0[(16 * hi + 4 * j + e) * TP + jl];
-#pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) {
-                            const float xb = (float)((xl[rb][j] >> (8 * e)) & 255u);
-                            facc[0][rb] = mfma32(row_next_ok[rb] ? fmaf(xb, s4[e], h4[e]) : 0.f, wt, facc[0][rb]);
-                        }
-                    }
-                }
-            }
-        }
         ch_wait_unit<12>(wq, mq, vq, ld);
         CH_STAMP(2)
 
@@ -531,24 +489,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         for (int r = 0; r < 16; ++r) g[r] = fmaf(gam, g[r], bet * dzs[r]);
         // Adam on the weight tile, stores, and the tile's transpose for the next forward
         const uint32_t so = unit_off(kt, ut);
-        // the deferred forward of the PREVIOUS k-tile (FWD_LAG): xhat_{t+1} of its SNPs 16 hi + 4 q + c (lane = row jl) times
-        // W'[SNP][unit jl] from this wave's Tw, one MFMA behind the Adam update of weight (q, c).  Branch-free: before the
-        // first tile (and without a next minibatch) both operands are zeros - Tw / ssw may hold anything then
-        const bool fwd_now = FWD_LAG && LOC_CHAIN_FWDLAG == 1 && lag_on;
-        u32x4 xl[RB];
-        if constexpr (FWD_LAG && LOC_CHAIN_FWDLAG == 1) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) xl[rb] = xrl[rb * 64 + lane];
-        }
         auto adam4 = [&](int q) {
-            f32x4 s4 = {0, 0, 0, 0}, h4 = {0, 0, 0, 0};
-            float wt[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (FWD_LAG && LOC_CHAIN_FWDLAG == 1) {
-                s4 = *reinterpret_cast<const f32x4*>(ssw + 16 * hi + 4 * q);
-                h4 = *reinterpret_cast<const f32x4*>(ssw + 32 + 16 * hi + 4 * q);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) wt[c] = Tw0[(16 * hi + 4 * q + c) * TP + jl];
-            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float wv = wq[q][c], mv = mq[q][c], vv = vq[q][c];
@@ -558,16 +499,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
                 ch_adam_fast(wv, mv, vv, g[q * 4 + c], alpha);
 #endif
                 wq[q][c] = wv; mq[q][c] = mv; vq[q][c] = vv;
-                if constexpr (FWD_LAG && LOC_CHAIN_FWDLAG == 1 && !(LOC_CHAIN_ABLATE & 4)) {
-                    const float wtc = fwd_now ? wt[c] : 0.f;
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const float xb = (float)((xl[rb][q] >> (8 * c)) & 255u);
-                        // rows beyond the next minibatch: staged from row 0, unused
-                        const float a = (fwd_now && row_next_ok[rb]) ? fmaf(xb, s4[c], h4[c]) : 0.f;
-                        facc[0][rb] = mfma32(a, wtc, facc[0][rb]);
-                    }
-                }
             }
         };
         // 12 stores, always
@@ -620,12 +551,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             }
             ssw[lane] = hi ? shn : scn;
             __builtin_amdgcn_wave_barrier();
-            if constexpr (FWD_LAG) {
-                // the tile's forward runs inside the next step (or behind the loop): keep its genotype bytes in this wave's slot
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) xrl[rb * 64 + lane] = xr[rb];
-                lag_on = true;
-            } else {
             // xhat of the next minibatch for SNPs 16*hi + s of the tile (lane = row jl), times W'[SNP][unit = jl]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -646,7 +571,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
                         for (int rb = 0; rb < RB; ++rb) facc[u][rb] = mfma32(a[rb], wt, facc[u][rb]);
                     }
                 }
-            }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -677,27 +601,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     }
     // the last iteration's dummy requests are still in flight: nothing below may reuse their registers before they land
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (FWD_LAG) {
-        if (lag_on && !(LOC_CHAIN_ABLATE & 4)) {        // the forward of this workgroup's last k-tile
-            u32x4 xl[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) xl[rb] = xrl[rb * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssw + 16 * hi + 4 * j);
-                const f32x4 h4 = *reinterpret_cast<const f32x4*>(ssw + 32 + 16 * hi + 4 * j);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float wt = Tw0[(16 * hi + 4 * j + e) * TP + jl];
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const float xb = (float)((xl[rb][j] >> (8 * e)) & 255u);
-                        facc[0][rb] = mfma32(row_next_ok[rb] ? fmaf(xb, s4[e], h4[e]) : 0.f, wt, facc[0][rb]);
-                    }
-                }
-            }
-        }
-    }
     if (chain) {
         // D[i = row b][j = unit]: lane holds unit w*32 + jl, rows rowmap(r, hi) -- the layout l1_reduce_kernel sums
         // (one partial group per k-tile slot of this workgroup: group g * KTW + slot)

@@ -114,12 +114,13 @@ def build_parser():
                         "converged fit, tests/test_gpu_trained_predict.py), else as exact; exact = 24-bit (as accurate as "
                         "fp32 accumulation; falls back to exactly-split bf16 when a unit's range exceeds 1024); fast = "
                         "16-bit unconditionally")
-    p.add_argument("--predict_packed", default=True, action="store_true",
-                   help="(default) keep a 2-bit packed copy of every genotype matrix that is predicted from over 3072 "
-                        "rows or more (values 0..3 only): such predictions read a quarter of the genotype bytes, with "
-                        "identical results; one extra pass over the matrix, once")
+    p.add_argument("--predict_packed", default=False, action="store_true",
+                   help="keep a 2-bit packed copy of every genotype matrix that is predicted from over 3072 rows or more "
+                        "(values 0..3 only): such predictions read a quarter of the genotype bytes, with identical results. "
+                        "Off by default since round 6: the one extra pass over the matrix costs as much as the packed form "
+                        "saves in about eight such predictions, and the CLI predicts from a matrix once or twice")
     p.add_argument("--no_predict_packed", dest="predict_packed", action="store_false",
-                   help="never keep the packed copy (saves a quarter of the matrix in device memory)")
+                   help="(default) never build the packed copy")
     p.add_argument("--predict_pieces", default=None, type=int,
                    help="force the bf16 matrix pipe with this many pieces per first-layer weight instead: 3 = "
                         "fp32-exact products, 1 or 2 = faster, approximate (default: bf16 x 3 only where the int8 "
@@ -279,7 +280,7 @@ class Model:
             net.X, start = gen.X, gen.start
         else:
             net.X, start = upload_genotypes(np.asarray(gen), self.device), 0
-        net.auto_pack = bool(getattr(args, "predict_packed", True))   # the packed copy is cached on the matrix itself
+        net.auto_pack = bool(getattr(args, "predict_packed", False))  # opt-in; the packed copy is cached on the matrix itself
         net.cnet()
         rows = torch.arange(start, start + n, dtype=torch.int32, device=self.device)
         yhat = torch.zeros((n, 2), dtype=torch.float32, device=self.device)

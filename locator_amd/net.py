@@ -116,7 +116,12 @@ class LocatorNet:
         self.l1_image = None               # image of s_k*W1 for many-row predicts (allocated on first use)
         self._image_mode = 0               # loc_predict_image_mode() of the image l1_image holds for the current parameters
         self._guard = None                 # (median R, max R, digits allowed, digits allowed in exact mode) of the current parameters
-        self.auto_pack = True              # many-row predicts keep a 2-bit packed copy of a matrix whose values are <= 3
+        # many-row predicts build a 2-bit packed copy of the matrix on their own only when asked (--predict_packed /
+        # pack_genotypes()): measured in round 6 (profiles/r06_gemm_packed_crossover.jsonl, medians of interleaved replays) the
+        # packed GEMM is 2-12 % faster on rows that stream from HBM and 3-6 % SLOWER on rows that repeat a cache-resident matrix,
+        # while the packing pass costs 21 us per 100 MB - eight 4096-row predicts' worth of the gain.  Rounds 4-5 packed from
+        # 3072 rows automatically; a matrix that is predicted from once (every CLI flow) lost by it.
+        self.auto_pack = False
         self.slot_rows = LOC_ROWS          # rows per activation slot; set_batch() widens it for --batch_size > 32
         self._net = None
         self.init_weights()
@@ -449,7 +454,8 @@ class LocatorNet:
     def pack_genotypes(self):
         """Keep a 2-bit packed copy of X (four genotypes per byte) next to it: many-row predicts of at least
         LOC_GEMM_I8_PACKED_MIN_ROWS (3072) rows per chunk then stream a quarter of the genotype bytes, with bit-identical
-        activations.  One pass over X (21 us per 100 MB): worth it for a matrix that is predicted from repeatedly.
+        activations.  One pass over X (21 us per 100 MB) against 11 us saved per 4096-row predict and 67 us per 16,384-row
+        one over rows that stream from HBM: worth it for a large matrix predicted from about ten times or more (opt-in).
         Returns False (and does nothing) when X holds values above 3."""
         if getattr(self.X, "loc_x2", None) is not None:
             return True

@@ -687,6 +687,10 @@ class ReplicatePool:
             f"serial part {serial:.1f} s = {100 * s['serial_fraction']:.0f} % of the wall",
             "  Amdahl projection at this serial part, same workers per GPU: " +
             ", ".join(f"{g} GPU {v:.1f} s ({s['amdahl_speedup_vs_1gpu'][g]:.2f}x)" for g, v in s["amdahl_projection_seconds"].items())]
+        aff = sorted({f"GPU {w['gpu']} -> {w['cpu_affinity']}" for w in tl["workers"] if w.get("cpu_affinity")})
+        if tl["workers"]:
+            s["lines"].append(f"  workers: {self.start_method} start, one visible device each (HIP_VISIBLE_DEVICES)"
+                              + (", CPU affinity from the device's PCI node: " + "; ".join(aff[:8]) if aff else ""))
         return s
 
 

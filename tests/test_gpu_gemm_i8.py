@@ -408,7 +408,6 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
     matrix with a genotype above 3 is left unpacked."""
     x, y, p, rng = make_problem(700, 6000, 256, 4, seed=12)
     net = build_net(x, y, p)
-    net.auto_pack = False                      # since round 4 a many-row predict packs the matrix on its own: off for the reference pass
     rows = torch.from_numpy(rng.integers(0, 700, 4096).astype(np.int32)).cuda()
     out = {}
     for packed in (False, True):
@@ -427,9 +426,14 @@ def test_predict_reads_the_packed_matrix_when_it_is_there_and_gives_the_same_bit
     x2[3, 17] = 4
     net2 = build_net(x2, y, p)
     assert net2.pack_genotypes() is False and getattr(net2.X, "loc_x2", None) is None
-    # the default: the first predict of >= 3072 rows packs the matrix itself (and a smaller one does not)
+    # the default since round 6: no predict packs the matrix on its own (the pass costs eight predicts' worth of the gain);
+    # with auto_pack (--predict_packed) the first predict of >= 3072 rows does, a smaller one does not
     net3 = build_net(x, y, p)
     yhat = torch.zeros((4096, 2), device="cuda")
+    net3.predict_rows(rows, 4096, yhat)
+    torch.cuda.synchronize()
+    assert getattr(net3.X, "loc_x2", None) is None and np.array_equal(yhat.cpu().numpy(), out[(False, 4096)])
+    net3.auto_pack = True
     net3.predict_rows(rows, 1000, yhat)
     assert getattr(net3.X, "loc_x2", None) is None
     net3.predict_rows(rows, 4096, yhat)

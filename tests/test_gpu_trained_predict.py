@@ -81,10 +81,11 @@ def _with_outliers(p32, factor, seed=5):
     return q
 
 
-def _predict_dev(X, Y, p32, n_rows, reps, **kw):
+def _predict_dev(X, Y, p32, n_rows, reps, packed=False, **kw):
     from locator_amd.net import LocatorNet
     K = p32["W"][0].shape[0]
     net = LocatorNet(X, Y, K, 256, 10, 0.25, seed=1, **kw)
+    net.auto_pack = packed                 # --predict_packed (opt-in since round 6)
     net.import_params(p32)
     n = n_rows * reps
     rows = torch.from_numpy((np.random.default_rng(3).permutation(n) % n_rows).astype(np.int32)).cuda()
@@ -106,7 +107,7 @@ def _range_stats(p32):
 MODES = {"auto": {"predict_digits": 0}, "exact": {"predict_digits": 3}, "fast": {"predict_digits": 2}}
 
 
-def _check(x, X, Y, p32, reps, label, expect_auto_digits, fast_must_hold=True):
+def _check(x, X, Y, p32, reps, label, expect_auto_digits, fast_must_hold=True, packed=False):
     p = O.cast_params(p32, np.float64)
     R = _range_stats(p32)
     ref_all = O.predict(p, x, batch=250)
@@ -116,7 +117,7 @@ def _check(x, X, Y, p32, reps, label, expect_auto_digits, fast_must_hold=True):
           f"(against the plain rms: {np.median(Rr):.1f} / {Rr.max():.1f}); |pred| max {pmax:.3f}")
     out = {}
     for mode, kw in MODES.items():
-        net, r, yhat = _predict_dev(X, Y, p32, x.shape[0], reps, **kw)
+        net, r, yhat = _predict_dev(X, Y, p32, x.shape[0], reps, packed=packed, **kw)
         dev = np.abs(yhat.astype(np.float64) - ref_all[r])
         err, rms = float(dev.max()), float(np.sqrt((dev ** 2).mean()))
         g = net._guard
@@ -140,8 +141,10 @@ def test_trained_metric_net_all_modes(trained_metric):
     x, X, Y, p32 = trained_metric
     out = _check(x, X, Y, p32, 1, "metric fit, 1000 rows", expect_auto_digits=2)
     assert out["auto"][1] <= 3e-4            # the measured margin, so a regression shows long before the bound
-    _check(x, X, Y, p32, 5, "metric fit, 5000 rows (packed genotypes)", expect_auto_digits=2)
-    assert getattr(X, "loc_x2", None) is not None        # the many-row predict packed the matrix on its own
+    _check(x, X, Y, p32, 5, "metric fit, 5000 rows", expect_auto_digits=2)
+    assert getattr(X, "loc_x2", None) is None            # no predict packs the matrix on its own (round 6)
+    _check(x, X, Y, p32, 5, "metric fit, 5000 rows (--predict_packed: 2-bit packed genotypes)", expect_auto_digits=2, packed=True)
+    assert getattr(X, "loc_x2", None) is not None
 
 
 def test_trained_fixture_net_all_modes(trained_fixture):

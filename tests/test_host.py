@@ -790,7 +790,7 @@ def test_pool_overlaps_host_work_with_the_previous_fit_and_reports_a_timeline():
     s = pool.summary(res)
     assert s["units"] == 6 and s["workers"] == 2 and 2.0 < s["unit_work_seconds"] < 3.5
     assert abs(s["host_prepare_seconds_total"] - 2.4) < 0.6 and 0 <= s["serial_fraction"] < 1
-    assert s["amdahl_projection_seconds"][8] < s["amdahl_projection_seconds"][1] and len(s["lines"]) == 3
+    assert s["amdahl_projection_seconds"][8] < s["amdahl_projection_seconds"][1] and len(s["lines"]) == 4 and "forkserver start" in s["lines"][3]
     assert len(pool.timeline["workers"]) == 2 and all(w["ready"] >= w["spawned"] for w in pool.timeline["workers"])
 
 
