@@ -561,14 +561,16 @@ def _snps_hint(unit):
     return 0
 
 
-def _fit_unit(unit, device="cuda:0"):
+def _fit_unit(unit, device="cuda:0", reraise=False):
     """_fit_unit_body under the process-wide device lock (train.DEVICE_LOCK): when several fits share a process, one thread
     and stream each, everything a fit does on the device outside its epoch loop - upload, net construction, read-backs,
     predict launches, and the destruction of its graphs / events / buffers when the body returns OR RAISES - is kept apart
     from a sibling's HIP-graph capture.  The epoch loop itself runs with the lock released (FitLoop.run), and so does the
     unit's pure host work (output files, plots: _host_io).  Before that the unit waits for admission (_FitBudget:
     --fits_per_gpu, or 3 / 2 at a time by the unit's own SNP count) - without holding the lock - and only then reports
-    ("start", index) to the pool through unit["on_admitted"], so --unit_timeout times the fit, not the wait for a sibling."""
+    ("start", index) to the pool through unit["on_admitted"], so --unit_timeout times the fit, not the wait for a sibling.
+    A failed fit comes back as an error record (what the pool collects); reraise=True (the single fit of a plain run) lets
+    the exception through instead - after the same teardown under the lock."""
     import traceback
     from .train import DEVICE_LOCK
     budget = _fit_slots(device)
@@ -585,6 +587,8 @@ def _fit_unit(unit, device="cuda:0"):
                 # under the lock, not later in a handler that runs while a sibling has a capture open.
                 rec = {"name": unit.get("name", "?"), "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()}
                 traceback.clear_frames(e.__traceback__)
+                if reraise:
+                    raise
                 del e
                 return rec
     finally:
@@ -925,7 +929,7 @@ def _main_body(pool, t_program):
         unit = dict(name="single", replicate=0, boot=0, out=args.out, traingen=traingen, testgen=testgen,
                     predgen=predgen, trainlocs=trainlocs, testlocs=testlocs, pred=pred, samples=samples,
                     sdlong=sdlong, meanlong=meanlong, sdlat=sdlat, meanlat=meanlat, args=args)
-        r = _fit_unit(unit)
+        r = _fit_unit(unit, reraise=True)
         plot_history(_H(r["history"]), r["dists"])
     elif args.bootstrap:
         units = _bootstrap_units(traingen.shape[1])
