@@ -24,7 +24,7 @@ The JSON line also carries
   roofline      the dominant kernel (l1_bwd_adam: fused layer-1 backward + Adam): algorithmic bytes per launch / its
                 mean duration from HIP events recorded on the launch stream immediately before and after that
                 kernel, vs 8 TB/s HBM.  `traffic` = PMC-measured bytes per launch from the committed rocprofv3
-                passes (profiles/r05_pmc_traffic.json), reported only while the kernel sources still hash to what
+                passes (profiles/r06_pmc_traffic.json), reported only while the kernel sources still hash to what
                 was profiled (`traffic_source` says which).
   cpu_baseline  the torch-CPU fp32 restatement of the same epochs (oracle/torch_cpu.py: "restated reference on CPU
                 (torch), not TensorFlow") on this box's physical cores, validation sweep included,
@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA peak (no sparsity)
-TRAFFIC_PROFILE = os.path.join("profiles", "r05_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r06_pmc_traffic.json")
 TRAFFIC_SOURCES = ("locator_amd/csrc/l1_kernels.hip", "locator_amd/csrc/l1_chain.hip", "locator_amd/csrc/common.h")
 
 

@@ -10,7 +10,7 @@
 #   gpurun_out/<tag>_gemm_pmc_1000.json, _4096.json, <tag>_gemm_kernel_stats.csv   large-M GEMM counters (with the effective
 #                                                 clock from GRBM_GUI_ACTIVE) and kernel times, int8 and bf16 kernels
 # Copy what should be judged into profiles/ (tracked).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -57,3 +57,12 @@ python3 bench.py --steps 40 --warmup 5 --sync-epochs --no-cpu-baseline --no-l1-g
 tail -c 1500 $O/${TAG}_bench_default.json; echo; cat $O/${TAG}_bench_replicates2.json | cut -c1-200; echo; cat $O/${TAG}_bench_2ranks_selflaunch.json | cut -c1-300; echo
 head -12 $O/${TAG}_bench_kernel_stats.csv | cut -c1-150
 tail -6 $O/pmc_traffic.log; tail -4 $O/gemm_pmc.log | cut -c1-400
+# round 6 evidence (profiles/r06_*): the probes of the chained layer-1 kernel (each a one-translation-unit measurement build next
+# to the product library: cache direction, cycle stamps), the packed-genotype crossover of the int8 GEMM (interleaved medians),
+# configs[3] with forkserver / spawn / in-process workers.  The stagger / early-request / lagged-forward probes of round 6 were
+# run from tools/probes/r06_probe*.sh on the commits named in docs/history/round6.md.
+( cd $R/locator_amd/csrc && make variant F=l1_chain XDEF=-DLOC_CHAIN_ALT=1 TAG=chalt > /dev/null 2>&1 && make variant F=l1_chain XDEF=-DLOC_CHAIN_STAMPS=100 TAG=chstamps > /dev/null 2>&1 )
+bash tools/chain_direction.sh > $O/${TAG}_chain_direction.jsonl 2>/dev/null
+python3 tools/probes/chain_stamps.py build/liblocator_hip_chstamps.so > $O/${TAG}_chain_stamps.txt 2>/dev/null
+python3 tools/gemm_packed_crossover.py --out $O/${TAG}_gemm_packed_crossover.jsonl > /dev/null 2>&1
+OUT=gpurun_out/${TAG}_config4_workers.txt bash tools/probes/r06_config4.sh > /dev/null 2>&1
