@@ -101,7 +101,6 @@ extern "C" int64_t loc_workspace_floats_batch(const loc_dims* d, int batch) {
 }
 extern "C" int64_t loc_workspace_floats(const loc_dims* d) { return loc_workspace_floats_batch(d, LOC_BATCH_SLOT); }
 
-int loc_warm_read_launch(const void* p, int64_t bytes, int blocks, void* stream);
 #define TRY(x)                 \
     do {                       \
         int rc__ = (x);        \
@@ -205,16 +204,6 @@ static int train_step_impl(const loc_net* net, const int32_t* rows, int n_b, int
         TRY(loc_stack_forward_backward(in_of(2), P + lay.wh, net->wht, P + lay.bh, P + lay.wa, P + lay.ba, P + lay.wb,
                                        P + lay.bb, use_drop ? mask : nullptr, ks, Hp, L, npre, n_b, slot, rows, net->Y,
                                        w.acts, w.adrop, w.dz, w.head_out, &net->tune, stream));
-#ifdef LOC_WARM_MOMENTS
-        // probe: LOC_WARM_MOMENTS = percent of (m, then v) of the first layer read into the Infinity Cache right before the
-        // chained kernel (serially here; in a product it would run beside the hidden stack, when HBM idles)
-        if (chain) {
-            const int64_t one = (int64_t)d->Kp * Hp * 4, want = 2 * one * LOC_WARM_MOMENTS / 100;
-            const int64_t nm = want < one ? want : one, nv = want - nm;
-            if (nm > 0) TRY(loc_warm_read_launch(M + lay.w1, nm & ~(int64_t)15, 2048, stream));
-            if (nv > 0) TRY(loc_warm_read_launch(V + lay.w1, nv & ~(int64_t)15, 2048, stream));
-        }
-#endif
         if (ev_l1b0) (void)hipEventRecord((hipEvent_t)ev_l1b0, (hipStream_t)stream);
         if (chain) {
             // layer-1 backward + Adam (W1, b1, gamma, beta, the next step's scale/shift) and -- rows_next given -- the

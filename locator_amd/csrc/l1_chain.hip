@@ -68,14 +68,6 @@
 #ifndef LOC_CHAIN_EARLY
 #define LOC_CHAIN_EARLY 0
 #endif
-// probe: the first / second Adam moment's LOADS with the default cache policy whatever the mask says (a warm-up kernel has just
-// read them into the Infinity Cache: api.hip -DLOC_WARM_MOMENTS)
-#ifndef LOC_CHAIN_M_DEFAULT
-#define LOC_CHAIN_M_DEFAULT 0
-#endif
-#ifndef LOC_CHAIN_V_DEFAULT
-#define LOC_CHAIN_V_DEFAULT 0
-#endif
 
 // -DLOC_CHAIN_STAMPS=<workgroup>: a measurement build (tools/probes/chain_stamps.py) in which every wave of one workgroup leaves
 // the cycle counter at eight points of every k-tile iteration (results unchanged)
@@ -260,10 +252,10 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // ONE address for the whole wave (one 16-byte request each instead of 1 KB), a different line per wave so that
         // the 2048 waves do not queue on one channel; results unused
         const uint32_t o = kt >= 0 ? unit_off(kt, ut) : (uint32_t)((((uint32_t)blockIdx.x * 8 + w) & 2047u) * 64u);
-        ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0 && !LOC_CHAIN_M_DEFAULT>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0 && !LOC_CHAIN_V_DEFAULT>(vq[0], v1s, o);
-        ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0 && !LOC_CHAIN_M_DEFAULT>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0 && !LOC_CHAIN_V_DEFAULT>(vq[1], v1s, o);
-        ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0 && !LOC_CHAIN_M_DEFAULT>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0 && !LOC_CHAIN_V_DEFAULT>(vq[2], v1s, o);
-        ch_gload16<3072, (NTM & 2) != 0>(wq[3], w1s, o); ch_gload16<3072, (NTM & 1) != 0 && !LOC_CHAIN_M_DEFAULT>(mq[3], m1s, o); ch_gload16<3072, (NTM & 1) != 0 && !LOC_CHAIN_V_DEFAULT>(vq[3], v1s, o);
+        ch_gload16<0, (NTM & 2) != 0>(wq[0], w1s, o);    ch_gload16<0, (NTM & 1) != 0>(mq[0], m1s, o);    ch_gload16<0, (NTM & 1) != 0>(vq[0], v1s, o);
+        ch_gload16<1024, (NTM & 2) != 0>(wq[1], w1s, o); ch_gload16<1024, (NTM & 1) != 0>(mq[1], m1s, o); ch_gload16<1024, (NTM & 1) != 0>(vq[1], v1s, o);
+        ch_gload16<2048, (NTM & 2) != 0>(wq[2], w1s, o); ch_gload16<2048, (NTM & 1) != 0>(mq[2], m1s, o); ch_gload16<2048, (NTM & 1) != 0>(vq[2], v1s, o);
+        ch_gload16<3072, (NTM & 2) != 0>(wq[3], w1s, o); ch_gload16<3072, (NTM & 1) != 0>(mq[3], m1s, o); ch_gload16<3072, (NTM & 1) != 0>(vq[3], v1s, o);
     };
     // The first unit is requested before anything else; the prologue ends with vmcnt(0).
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];

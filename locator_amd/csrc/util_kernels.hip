@@ -375,20 +375,3 @@ extern "C" int loc_kde_peak_batch(const double* xy, const int64_t* offsets, int 
     LOC_CHECK_LAUNCH();
     return 0;
 }
-
-// Read `bytes` of device memory and discard them (default cache policy): a measurement aid - what is a chained step worth when a
-// stream it reads has just been pulled into the Infinity Cache?  (round 6 probe, api.hip -DLOC_WARM_MOMENTS)
-__global__ __launch_bounds__(256) void warm_read_kernel(const f32x4* __restrict__ p, int64_t n4) {
-    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = p[i];
-        sink[0] += v[0];
-    }
-    asm volatile("" ::"v"(sink[0]));
-}
-int loc_warm_read_launch(const void* p, int64_t bytes, int blocks, void* stream) {
-    hipLaunchKernelGGL(warm_read_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(p),
-                       bytes / 16);
-    LOC_CHECK_LAUNCH();
-    return 0;
-}
