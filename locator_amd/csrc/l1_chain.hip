@@ -58,31 +58,6 @@
 #define LOC_CHAIN_ABLATE 0
 #endif
 
-// probe (make variant F=l1_chain XDEF=-DLOC_CHAIN_ALT=1): odd Adam steps walk their k-tiles last first
-#ifndef LOC_CHAIN_ALT
-#define LOC_CHAIN_ALT 0
-#endif
-// probe (make variant F=l1_chain XDEF=-DLOC_CHAIN_EARLY=1; one unit tile per wave only): the unit after next is requested right
-// behind the k-tile's barrier, into the register set whose stores have just been issued, instead of at the top of the next
-// iteration - a third more bytes in flight per wave while the forward part runs (same wait count: 12 younger loads)
-#ifndef LOC_CHAIN_EARLY
-#define LOC_CHAIN_EARLY 0
-#endif
-
-// -DLOC_CHAIN_STAMPS=<workgroup>: a measurement build (tools/probes/chain_stamps.py) in which every wave of one workgroup leaves
-// the cycle counter at eight points of every k-tile iteration (results unchanged)
-#ifdef LOC_CHAIN_STAMPS
-__device__ unsigned long long ch_stamp_buf[8 * 16 * 8];
-#define CH_STAMP(i)                                                                                                \
-    if ((int)blockIdx.x == LOC_CHAIN_STAMPS && (threadIdx.x & 63) == 0 && stamp_it < 16)                           \
-        ch_stamp_buf[((threadIdx.x >> 6) * 16 + stamp_it) * 8 + (i)] = __builtin_readcyclecounter();
-extern "C" int loc_debug_chain_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_stamp_buf), sizeof(unsigned long long) * 8 * 16 * 8);
-}
-#else
-#define CH_STAMP(i)
-#endif
-
 __device__ __forceinline__ void ch_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void ch_adam_fast(float& w, float& m, float& v, float g, float alpha) {
@@ -212,12 +187,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         stack_dw_all_body<NHT, RB == 1 ? 1 : 0>((int)blockIdx.x - G, ta, none);
         return;
     }
-#ifdef LOC_CHAIN_STAGGER
-    // probe: every other workgroup of an XCD starts LOC_CHAIN_STAGGER x ~1 us late (does taking the workgroups out of
-    // lockstep hide the arithmetic between a unit's arrival and the next request?)
-    if (((int)blockIdx.x >> 3) & 1)
-        for (int i = 0; i < LOC_CHAIN_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzl = smem;                                          // [NR][PZ]   dZ of this step
     int* rows_l = reinterpret_cast<int*>(dzl + NR * PZ);        // [NR]
@@ -240,10 +209,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     auto ktile = [&](int T, int slot) { return (T >= 0 && T < S && T * KTW + slot < nkt) ? T * KTW + slot : -1; };
     const float alpha = adam_alpha(alpha_tab, alpha_tab_len, lr, t_base, t_off);
     const bool chain = rows_next != nullptr;
-    const bool rev = LOC_CHAIN_ALT && (((t_base ? t_base[0] : 0) + t_off) & 1);
-    // the super-tiles this workgroup owns, in the order it walks them: g, g + G, ... (rev: the same ones, last first)
-    const int n_own = (int)blockIdx.x < S ? (S - 1 - (int)blockIdx.x) / G + 1 : 0;
-    auto tile_at = [&](int i) { return (i >= 0 && i < n_own) ? (int)blockIdx.x + (rev ? n_own - 1 - i : i) * G : -1; };
 
     // byte offset of this lane's first 16 bytes of unit (kt, w) in each of W1S / m / v  (Kp * 1024 < 2^32: checked by the launcher)
     auto unit_off = [&](int kt, int ut) { return (uint32_t)(((uint32_t)kt * NHT + ut) * 4096u + lane * 16u); };
@@ -259,7 +224,7 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     };
     // The first unit is requested before anything else; the prologue ends with vmcnt(0).
     f32x4 wA[4], mA[4], vA[4], wB[4], mB[4], vB[4];
-    load_unit(ktile(tile_at(0), kq), ut0, wA, mA, vA);
+    load_unit(ktile((int)blockIdx.x, kq), ut0, wA, mA, vA);
 
     if constexpr (RB == 1) {
         for (int i = t; i < 32 * Hp; i += 512) dzl[(i / Hp) * PZ + (i % Hp)] = dz1[i];
@@ -363,11 +328,11 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         }
     };
     {
-        const int T0 = tile_at(0);
+        const int T0 = blockIdx.x;
         fetch(T0);
         ch_wait_unit<0>(wA, mA, vA, ld);
         stage(0, T0);
-        fetch(tile_at(1));                                      // staged during the first iteration
+        fetch(T0 + G);                                          // staged during the first iteration
         ch_wait_unit<0>(wA, mA, vA, ld);
     }
     __syncthreads();
@@ -394,12 +359,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         }
     }
 
-#ifdef LOC_CHAIN_WSTAG
-    // probe (with LOC_CHAIN_ABLATE & 1 = no barrier; results wrong): the second wave of every SIMD enters the loop
-    // LOC_CHAIN_WSTAG x ~1 us late - what would two decoupled half-workgroups per compute unit buy?
-    if (w >= 4)
-        for (int i = 0; i < LOC_CHAIN_WSTAG; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
     float* Tw0 = Tt + w * UPW * 32 * TP;
     float* ssw = ssl + w * 64;
     bool row_next_ok[RB];
@@ -412,8 +371,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) facc[u][rb] = f32x16{0};
     float pg_acc = 0.f, pb_acc = 0.f;     // this wave's (dgamma | dbeta) partial over the sub-steps of a k-tile
-    int stamp_it = 0;                     // (measurement build: iteration number of the stamps)
-    (void)stamp_it;
 
     // Vector-memory operations of one sub-step, in program order (the hand-counted wait depends on it):
     //   12 prefetch loads | wait | 12 stores of this unit | last sub-step of the k-tile: 3 small loads of tile + 2 per role |
@@ -453,11 +410,8 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // ONE wait per iteration, right after the next unit's 12 loads (always 12: dummies on the last tile): "at most 12
         // outstanding" proves every older load landed -- this unit (requested an iteration ago) and the next tile's small
         // operands ld0..2 (requested at the end of the previous iteration).
-        CH_STAMP(0)
-        if (!(LOC_CHAIN_EARLY && UPW == 1)) load_unit(ktile(T_pref, kq), ut0 + WPS * ((SUB + 1) % UPW), wn, mn, vn);
-        CH_STAMP(1)
+        load_unit(ktile(T_pref, kq), ut0 + WPS * ((SUB + 1) % UPW), wn, mn, vn);
         ch_wait_unit<12>(wq, mq, vq, ld);
-        CH_STAMP(2)
 
         // ONE fp32 MFMA chain per unit:  Gn[h][k] = sum_b dZ[b][h] xn[b][k]  (D[i = unit][j = SNP], contraction over the
         // batch rows b = rowmap(s, hi); xn = (x - mean) * rstd).  Everything else follows from it without forming dxhat
@@ -484,7 +438,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             if (last) red[(par * 8 + w) * 64 + lane] = valid ? (hi ? pb : pg) : 0.f;
             else { pg_acc = pg; pb_acc = pb; }
         }
-        CH_STAMP(3)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = fmaf(gam, g[r], bet * dzs[r]);
         // Adam on the weight tile, stores, and the tile's transpose for the next forward
@@ -513,7 +466,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         adam4(3); ch_gstore16<3072, (NTM & 4) != 0>(wq[3], w1s, so); ch_gstore16<3072, (NTM & 8) != 0>(mq[3], m1s, so); ch_gstore16<3072, (NTM & 8) != 0>(vq[3], v1s, so);
         }
 #endif
-        CH_STAMP(4)
         if (chain && valid && !(LOC_CHAIN_ABLATE & 4)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tw[jl * TP + rowmap(r, hi)] = wq[r >> 2][r & 3];   // T[SNP][unit]
@@ -523,14 +475,11 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
         // the tile after next.
         if (!(LOC_CHAIN_ABLATE & 2)) stage(par ^ 1, T_next);
         fetch(T_next2);
-        CH_STAMP(5)
 #if !(LOC_CHAIN_ABLATE & 1)
         // every wave's (dgamma | dbeta) partial of this k-tile and the next tile's small operands are in LDS; all reads
         // of this tile's small operands are above this line, so the buffer is free for tile + 2 after it
         ch_lds_barrier();
 #endif
-        CH_STAMP(6)
-        if (LOC_CHAIN_EARLY && UPW == 1) load_unit(ktile(T_next2, kq), ut0, wq, mq, vq);
 
         float dsum = red[(par * 8 + kq * WPS) * 64 + lane];       // the waves of this slot, in wave order
 #pragma unroll
@@ -574,8 +523,6 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        CH_STAMP(7)
-        ++stamp_it;
     };
 
     // workgroup g owns k-tiles g, g + G, g + 2G, ...: at any moment the G workgroups stream one contiguous G * 32 KB
@@ -583,18 +530,17 @@ __global__ __launch_bounds__(512) void l1_bwd_adam_chain_kernel(
     {
         using sub0 = std::integral_constant<int, 0>;
         using sub1 = std::integral_constant<int, 1>;
-        if (LOC_CHAIN_EARLY && UPW == 1) load_unit(ktile(tile_at(1), kq), ut0, wB, mB, vB);
-        for (int i = 0; i < n_own; i += 2) {
-            auto nx = [&](int j) { return tile_at(i + j); };
+        for (int T = blockIdx.x; T < S; T += 2 * G) {
+            auto nx = [&](int j) { return T + j * G < S ? T + j * G : -1; };
             if constexpr (UPW == 1) {
-                step(sub0{}, nx(0), nx(1), nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
-                if (i + 1 < n_own) step(sub0{}, nx(1), nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+                step(sub0{}, T, nx(1), nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+                if (T + G < S) step(sub0{}, T + G, nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
             } else {
-                step(sub0{}, nx(0), nx(0), nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
-                step(sub1{}, nx(0), nx(1), nx(1), nx(2), 0, wB, mB, vB, wA, mA, vA);
-                if (i + 1 < n_own) {
-                    step(sub0{}, nx(1), nx(1), nx(2), nx(3), 1, wA, mA, vA, wB, mB, vB);
-                    step(sub1{}, nx(1), nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
+                step(sub0{}, T, T, nx(1), nx(2), 0, wA, mA, vA, wB, mB, vB);
+                step(sub1{}, T, nx(1), nx(1), nx(2), 0, wB, mB, vB, wA, mA, vA);
+                if (T + G < S) {
+                    step(sub0{}, T + G, T + G, nx(2), nx(3), 1, wA, mA, vA, wB, mB, vB);
+                    step(sub1{}, T + G, nx(2), nx(2), nx(3), 1, wB, mB, vB, wA, mA, vA);
                 }
             }
         }

@@ -1,5 +1,6 @@
-"""Phase timing inside l1_bwd_adam_chain_kernel (measurement build: -DLOC_CHAIN_STAMPS=<workgroup>, see l1_chain.hip).
-    make -C locator_amd/csrc variant F=l1_chain XDEF=-DLOC_CHAIN_STAMPS=100 TAG=chstamps
+"""Phase timing inside l1_bwd_adam_chain_kernel (measurement build: -DLOC_CHAIN_STAMPS=<workgroup> on the source with
+tools/probes/l1_chain_probes.patch applied).
+    bash tools/probes/build_chain_probe.sh chstamps -DLOC_CHAIN_STAMPS=100
     python3 tools/probes/chain_stamps.py build/liblocator_hip_chstamps.so
 Prints, per k-tile iteration of one workgroup (min..max over its 8 waves, shader cycles): issue of the 12 prefetch loads, the
 hand-counted wait, MFMA chain + reductions, Adam + 12 stores, transposes + staging, barrier, gamma / beta Adam + next forward."""

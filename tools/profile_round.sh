@@ -61,7 +61,8 @@ tail -6 $O/pmc_traffic.log; tail -4 $O/gemm_pmc.log | cut -c1-400
 # to the product library: cache direction, cycle stamps), the packed-genotype crossover of the int8 GEMM (interleaved medians),
 # configs[3] with forkserver / spawn / in-process workers.  The stagger / early-request / lagged-forward probes of round 6 were
 # run from tools/probes/r06_probe*.sh on the commits named in docs/history/round6.md.
-( cd $R/locator_amd/csrc && make variant F=l1_chain XDEF=-DLOC_CHAIN_ALT=1 TAG=chalt > /dev/null 2>&1 && make variant F=l1_chain XDEF=-DLOC_CHAIN_STAMPS=100 TAG=chstamps > /dev/null 2>&1 )
+bash tools/probes/build_chain_probe.sh chalt -DLOC_CHAIN_ALT=1 > /dev/null 2>&1
+bash tools/probes/build_chain_probe.sh chstamps -DLOC_CHAIN_STAMPS=100 > /dev/null 2>&1
 bash tools/chain_direction.sh > $O/${TAG}_chain_direction.jsonl 2>/dev/null
 python3 tools/probes/chain_stamps.py build/liblocator_hip_chstamps.so > $O/${TAG}_chain_stamps.txt 2>/dev/null
 python3 tools/gemm_packed_crossover.py --out $O/${TAG}_gemm_packed_crossover.jsonl > /dev/null 2>&1
