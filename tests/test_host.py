@@ -1041,3 +1041,35 @@ def test_native_host_filter_and_transposes_equal_the_numpy_restatement():
     v = G.read_vcf(VCF)["calldata/GT"]                         # the reference's example: 5,830 SNPs either way
     assert np.array_equal(G.filter_snps(v, 2, verbose=False), G.filter_snps(v, 2, verbose=False, native=False))
     assert G.filter_snps(v, 2, verbose=False).shape[0] == 5830
+
+
+def test_worker_gpu_binding_maps_the_parents_visible_list_and_counting_gpus_needs_no_torch(monkeypatch, tmp_path):
+    """replicates._bind_worker_to_gpu (one process per GPU through HIP_VISIBLE_DEVICES): worker g of a
+    parent that sees everything gets "g"; of a parent restricted by --gpu_number / HIP_VISIBLE_DEVICES the g-th entry of that
+    list - which travels explicitly, a forked worker inherits the fork server's environment; CUDA_VISIBLE_DEVICES is folded in
+    and removed.  visible_gpus() reads the KFD topology (nodes with simd_count > 0), narrowed by the same variables."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    R._bind_worker_to_gpu(3, {})
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "3" and "CUDA_VISIBLE_DEVICES" not in os.environ
+    R._bind_worker_to_gpu(1, {"HIP_VISIBLE_DEVICES": "4,6,7", "CUDA_VISIBLE_DEVICES": None})
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "6"
+    R._bind_worker_to_gpu(0, {"HIP_VISIBLE_DEVICES": None, "CUDA_VISIBLE_DEVICES": "5"})
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "5" and "CUDA_VISIBLE_DEVICES" not in os.environ
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,3")
+    assert R._visible_env()["HIP_VISIBLE_DEVICES"] == "2,3"
+    # a fake KFD topology: one CPU node, three GPU nodes
+    import glob as _glob
+    nodes = []
+    for i, simd in enumerate((0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+        nodes.append(str(d / "properties"))
+    monkeypatch.setattr(_glob, "glob", lambda pat: nodes if "kfd" in pat else [])
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert R.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert R.visible_gpus() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert R.visible_gpus() == 1
