@@ -234,7 +234,8 @@ def _worker(gpu, fit_fn, args, prepare, host_prepare, conn, t_parent, fit_thread
 
 def visible_gpus():
     """GPUs this process may use, counted WITHOUT importing torch or touching the GPU when the kernel driver's topology is
-    readable (/sys/class/kfd: a node with simd_count > 0 is a GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow it): the
+    readable (/sys/class/kfd: a node with simd_count > 0 whose render node this process may open is a GPU; HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES narrow it): the
     parent of a replicate run starts its workers first thing, and `import torch` alone is a second of that critical path."""
     import glob
     import os
@@ -243,7 +244,11 @@ def visible_gpus():
         for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
             with open(f) as fh:
                 props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
-            n += int(props.get("simd_count", "0")) > 0
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                     # a CPU node
+            # a container may see the whole host's topology but only some render nodes: a GPU counts when its device file does
+            minor = int(props.get("drm_render_minor", "-1"))
+            n += minor < 0 or os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK)
         if n > 0:
             for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
                 v = os.environ.get(var)

@@ -1069,6 +1069,15 @@ def test_worker_gpu_binding_maps_the_parents_visible_list_and_counting_gpus_need
     monkeypatch.setattr(_glob, "glob", lambda pat: nodes if "kfd" in pat else [])
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert R.visible_gpus() == 3
+    # a container that sees the host's topology but was given only some render nodes: a GPU counts when its device file opens
+    for i, minor in ((1, 128), (2, 129), (3, 130)):
+        with open(nodes[i], "a") as fh:
+            fh.write(f"drm_render_minor {minor}\n")
+    real_access = os.access
+    monkeypatch.setattr(os, "access", lambda path, mode: path.endswith("renderD129") if "/dev/dri/" in str(path) else real_access(path, mode))
+    assert R.visible_gpus() == 1
+    monkeypatch.setattr(os, "access", lambda path, mode: True if "/dev/dri/" in str(path) else real_access(path, mode))
+    assert R.visible_gpus() == 3
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
     assert R.visible_gpus() == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
