@@ -14,7 +14,9 @@ def _report_fit(unit, device="cpu"):
     """What a worker process sees: its device string, how many devices, the variable, whether torch was already imported
     when the process started working (fork server preload), and a kernel launch on the device it was given."""
     import sys
+    import time
     import torch
+    time.sleep(0.4)          # long enough for the second worker (a spawned one imports torch first) to take its share
     x = torch.arange(8, device=device, dtype=torch.float32)
     return {"name": unit["name"], "device": device, "count": torch.cuda.device_count(), "seconds": 0.0,
             "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "cuda_visible": os.environ.get("CUDA_VISIBLE_DEVICES"),
@@ -33,7 +35,7 @@ def _probe_visible(gpu, env, conn):
 
 @pytest.mark.parametrize("method", ["forkserver", "spawn"])
 def test_workers_see_exactly_their_own_device_as_cuda0(method):
-    units = [dict(name=f"u{i}", replicate=i) for i in range(4)]
+    units = [dict(name=f"u{i}", replicate=i) for i in range(10)]
     pool = R.ReplicatePool(_Args(), _report_fit, n_gpus=1, fits_per_gpu=2, procs_per_gpu=2, isolate=True, start_method=method,
                            log=lambda *a: None, poll_s=0.05)
     pool.start()
