@@ -22,7 +22,7 @@ for W in ${WORKERS:-2 1 4 8 16}; do
     rc=$?
     t2=$(date +%s%N)
     echo "=== fits_per_gpu $W: rc $rc, wall $(( (t2 - t1) / 1000000 )) ms, $(ls /tmp/c4out | grep -c predlocs) predlocs files" >> $O
-    grep -E "replicate phases|replicate timeline|units:|Amdahl|FAILED" /tmp/c4_w$W.log >> $O
+    grep -E "replicate phases|replicate timeline|units:|Amdahl|workers:|FAILED" /tmp/c4_w$W.log >> $O
     md5sum /tmp/c4out/*predlocs.txt | awk '{print $1}' | md5sum | awk '{print "    predlocs digest " $1}' >> $O
 done
 cat $O
