@@ -277,11 +277,17 @@ def warm_start(method=None):
     method = method or START_METHOD
     if method != "forkserver":
         return None
-    ctx = mp.get_context("forkserver")
-    ctx.set_forkserver_preload(list(_PRELOAD))
-    from multiprocessing import forkserver
-    forkserver.ensure_running()
-    return ctx
+    try:
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(list(_PRELOAD))
+        from multiprocessing import forkserver
+        forkserver.ensure_running()
+        return ctx
+    except (OSError, ValueError, ImportError) as e:          # no UNIX sockets / no fork server on this platform
+        import sys
+        print(f"replicate workers: fork server unavailable ({type(e).__name__}: {e}); spawning fresh interpreters instead",
+              file=sys.stderr)
+        return None
 
 
 def _visible_env():
