@@ -416,7 +416,9 @@ class ReplicatePool:
         # never touched a GPU (warm_start - locator.main calls it first thing, so the imports overlap the parent's start-up);
         # "spawn": a fresh interpreter per worker (rounds 1-5).
         import multiprocessing as mp
-        self.ctx = warm_start(self.start_method) or mp.get_context("spawn")
+        self.ctx = warm_start(self.start_method)
+        if self.ctx is None:
+            self.ctx, self.start_method = mp.get_context("spawn"), "spawn"
         for w in range(self.n):
             self._start_worker(w % self.n_g)
         return self
