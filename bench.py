@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--stack-helpers", type=int, default=0, help="loc_tuning.stack_helpers (L2 warm-up workgroups of the hidden stack; measurement switch)")
     ap.add_argument("--stack-xcd-stride", type=int, default=0, help="loc_tuning.stack_xcd_stride (1, 2, 4, 8: the hidden stack's workers share 8 / n XCDs; measurement switch)")
     ap.add_argument("--stack-train-rows", type=int, default=0, help="loc_tuning.stack_train_rows (1, 2, 4 batch rows per workgroup of the training stack; 0 = default)")
+    ap.add_argument("--epoch-times", action="store_true", help="measurement switch: host-observed completion interval of every timed epoch on stderr")
     ap.add_argument("--separate-tail", action="store_true",
                     help="measurement switch (loc_tuning.chain_tail = -1): the hidden-layer Adam tail of a chained step as "
                          "its own launch instead of trailing workgroups of the chained layer-1 launch")
@@ -435,6 +436,9 @@ def main():
     drain()                                    # every timed epoch's history row has been read back
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.epoch_times:
+        es = fits[0].loop.hist.epoch_seconds[-args.steps:]
+        print("epoch completion intervals of the timed epochs, ms:", " ".join(f"{1e3 * v:.2f}" for v in es), file=sys.stderr)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
